@@ -1,0 +1,300 @@
+"""Pin the oracle against the imported reference and write `tests/golden/*.npz`.
+
+Run ONLY in the build container (the reference lives at /root/reference and
+never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+For every case it (1) builds the reference `PINNModel` + `XxxEquation` under a
+fixed seed, (2) asserts that `oracle.reference_path` reproduces theta_0, the
+forward, `compute_derivatives`, the residual, mean(r^2) and dL/dtheta of the
+reference (bit-for-bit where the op sequence is identical), and (3) stores the
+inputs and the REFERENCE's outputs (fp32 and an fp64 twin) as a fixture.  The
+fixtures are data only — no reference source text.
+"""
+
+from __future__ import annotations
+
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from pinnrl.config import Config, ModelConfig  # noqa: E402  (reference)
+from pinnrl.neural_networks import PINNModel  # noqa: E402
+from pinnrl.pdes.allen_cahn import AllenCahnEquation  # noqa: E402
+from pinnrl.pdes.black_scholes import BlackScholesEquation  # noqa: E402
+from pinnrl.pdes.burgers_equation import BurgersEquation  # noqa: E402
+from pinnrl.pdes.cahn_hilliard import CahnHilliardEquation  # noqa: E402
+from pinnrl.pdes.convection_equation import ConvectionEquation  # noqa: E402
+from pinnrl.pdes.heat_equation import HeatEquation  # noqa: E402
+from pinnrl.pdes.kdv_equation import KdVEquation  # noqa: E402
+from pinnrl.pdes.pde_base import PDEConfig  # noqa: E402
+from pinnrl.pdes.pendulum_equation import PendulumEquation  # noqa: E402
+from pinnrl.pdes.wave_equation import WaveEquation  # noqa: E402
+
+from oracle import reference_path as O  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+CPU = torch.device("cpu")
+
+PDE_CLS = {
+    "heat": HeatEquation,
+    "burgers": BurgersEquation,
+    "allen_cahn": AllenCahnEquation,
+    "kdv": KdVEquation,
+    "cahn_hilliard": CahnHilliardEquation,
+    "wave": WaveEquation,
+    "convection": ConvectionEquation,
+    "black_scholes": BlackScholesEquation,
+    "pendulum": PendulumEquation,
+}
+
+PDE_DEFAULTS = {
+    # name: (domain, time_domain, parameters, initial_condition)
+    "heat": ([(0.0, 1.0)], (0.0, 1.0), {"alpha": 0.01}, {"type": "sine", "amplitude": 1.0, "frequency": 2.0}),
+    "burgers": ([(-1.0, 1.0)], (0.0, 1.0), {"nu": 0.01 / math.pi}, {"type": "sine", "amplitude": -1.0, "frequency": 1.0}),
+    "allen_cahn": ([(-1.0, 1.0)], (0.0, 1.0), {"epsilon": 0.01}, {"type": "tanh", "epsilon": 0.1}),
+    "kdv": ([(-15.0, 15.0)], (0.0, 5.0), {"speed": 1.0}, {"type": "soliton", "speed": 1.0}),
+    "cahn_hilliard": ([(0.0, 1.0)], (0.0, 1.0), {"epsilon": 0.01}, {"type": "tanh"}),
+    "wave": ([(0.0, 1.0)], (0.0, 1.0), {"c": 1.0}, {"type": "sine", "amplitude": 1.0, "frequency": 1.0}),
+    "convection": ([(0.0, 2.0)], (0.0, 1.0), {"velocity": [1.0]}, {"type": "sine", "amplitude": 1.0, "frequency": 1.0}),
+    "black_scholes": ([(0.0, 200.0)], (0.0, 1.0), {"sigma": 0.2, "r": 0.05}, {"type": "call_option", "strike_price": 100.0}),
+    "pendulum": ([(0.0, 1.0)], (0.0, 10.0), {"g": 9.81, "L": 1.0}, {"type": "small_angle", "initial_angle": 0.5}),
+}
+
+
+def make_ref_model(spec: O.ArchSpec):
+    cfg = Config.__new__(Config)
+    cfg.device = CPU
+    cfg.model = ModelConfig(
+        input_dim=spec.input_dim,
+        hidden_dim=spec.hidden_dim,
+        output_dim=spec.output_dim,
+        num_layers=spec.num_layers,
+        activation=spec.activation,
+        dropout=0.0,
+        layer_norm=spec.layer_norm,
+        architecture=spec.architecture,
+    )
+    cfg.model.mapping_size = spec.mapping_size
+    cfg.model.scale = spec.scale
+    cfg.model.omega_0 = spec.omega_0
+    cfg.model.num_heads = spec.num_heads
+    if spec.architecture == "resnet":
+        cfg.model.num_blocks = spec.num_blocks if spec.num_blocks is not None else spec.num_layers
+    cfg.model.device = CPU
+    return PINNModel(cfg, device=CPU)
+
+
+def make_ref_pde(pde: O.PdeSpec):
+    cfg = PDEConfig(
+        name=pde.name,
+        domain=[tuple(d) for d in pde.domain],
+        time_domain=tuple(pde.time_domain),
+        parameters=dict(pde.parameters),
+        boundary_conditions=dict(pde.boundary_conditions),
+        initial_condition=dict(pde.initial_condition),
+        exact_solution={},
+        dimension=pde.dimension,
+        device=CPU,
+    )
+    return PDE_CLS[pde.name](config=cfg)
+
+
+def pde_spec(name: str, dimension: int = 1) -> O.PdeSpec:
+    dom, td, par, ic = PDE_DEFAULTS[name]
+    if dimension > 1:
+        dom = [dom[0]] * dimension
+    return O.PdeSpec(
+        name=name,
+        dimension=dimension,
+        domain=dom,
+        time_domain=td,
+        parameters=par,
+        boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}},
+        initial_condition=ic,
+    )
+
+
+def points(pde: O.PdeSpec, ref_pde, n: int, seed: int):
+    """`n` reference-sampled points + the domain corners (adversarial: clamp edges)."""
+    torch.manual_seed(seed)
+    x, t = ref_pde.generate_collocation_points(n, strategy="uniform")
+    torch.manual_seed(seed)
+    xo, to = O.sample_uniform(pde, n)
+    assert torch.equal(x, xo) and torch.equal(t, to), "sample_uniform restatement differs from the reference"
+    lo = torch.tensor([[d[0] for d in pde.domain[: pde.dimension]]], dtype=torch.float32)
+    hi = torch.tensor([[d[1] for d in pde.domain[: pde.dimension]]], dtype=torch.float32)
+    t0, t1 = pde.time_domain
+    xc = torch.cat([lo, lo, hi, hi, (lo + hi) / 2], 0)
+    tc = torch.tensor([[t0], [t1], [t0], [t1], [(t0 + t1) / 2]], dtype=torch.float32)
+    return torch.cat([x, xc], 0).contiguous(), torch.cat([t, tc], 0).contiguous()
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / max(b.norm().item(), 1e-30))
+
+
+def run_case(tag: str, spec: O.ArchSpec, pde: O.PdeSpec, n_pts: int, seed: int, manifest: dict):
+    torch.manual_seed(seed)
+    model = make_ref_model(spec)
+    ref_pde = make_ref_pde(pde)
+    sd_ref = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    # (1) theta_0 restatement
+    sd_o = O.init_state_dict(spec, seed=seed)
+    assert list(sd_o.keys()) == list(sd_ref.keys()), (tag, list(sd_o.keys()), list(sd_ref.keys()))
+    for k in sd_ref:
+        assert torch.equal(sd_o[k], sd_ref[k]), f"{tag}: init of {k} differs"
+
+    x, t = points(pde, ref_pde, n_pts, seed + 1)
+
+    # (2) forward
+    inp = torch.cat([x, t], 1)
+    u_ref = model(inp).detach()
+    u_o = O.network_forward(spec, sd_ref, inp)
+    assert torch.equal(u_ref, u_o), f"{tag}: forward differs ({rel_l2(u_o, u_ref):.2e})"
+
+    # (3) residual + loss + gradient, reference
+    model.zero_grad()
+    r_ref = ref_pde.compute_residual(model, x.clone(), t.clone())
+    L_ref = ref_pde._apply_loss_fn(r_ref)
+    L_ref.backward()
+    names = [k for k, p in model.named_parameters()]
+    g_ref = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()}
+
+    r_o, L_o, g_o = O.residual_loss_and_grad(pde, spec, sd_ref, x.clone(), t.clone())
+    e_r, e_L = rel_l2(r_o, r_ref.detach()), abs(float(L_o) - float(L_ref.detach())) / max(abs(float(L_ref.detach())), 1e-30)
+    e_g = max(rel_l2(g_o[k], g_ref[k]) if g_ref[k].norm() > 0 else float(g_o[k].abs().max()) for k in names)
+    assert e_r <= 1e-6 and e_L <= 1e-6 and e_g <= 2e-5, f"{tag}: restatement off: r {e_r:.2e} L {e_L:.2e} g {e_g:.2e}"
+
+    # (4) derivative dictionary of the reference (jets) for the stream set this PDE uses
+    jets = {}
+    want_t, want_x = {"wave": [1, 2], "pendulum": [1, 2]}.get(pde.name, [1]), {
+        "heat": [1, 2], "burgers": [1, 2], "allen_cahn": [1, 2], "kdv": [1, 2, 3], "cahn_hilliard": [1, 2, 3, 4],
+        "wave": [1, 2], "convection": [1], "black_scholes": [1, 2], "pendulum": [],
+    }[pde.name]
+    if pde.dimension == 1:
+        d = ref_pde.compute_derivatives(model, x, t, temporal_derivatives=want_t, spatial_derivatives=want_x)
+        d_o = O.compute_derivatives(lambda z: O.network_forward(spec, sd_ref, z), x, t, want_t, want_x, 1)
+        for k, v in d.items():
+            assert torch.equal(v.detach(), d_o[k].detach()), f"{tag}: derivative {k} differs"
+            jets["jet_" + k] = v.detach().numpy()
+    else:
+        d = ref_pde.compute_derivatives(model, x, t, temporal_derivatives=[1], spatial_derivatives=[])
+        jets["jet_dt"] = d["dt"].detach().numpy()
+
+    # (5) fp64 twin (the arbiter for tolerance-based parity)
+    model64 = make_ref_model(spec).double()
+    model64.load_state_dict({k: v.double() for k, v in sd_ref.items()})
+    # Fourier keeps B as a buffer that forward() may re-place; make sure it is double
+    for mod in model64.modules():
+        if hasattr(mod, "B"):
+            mod.B = mod.B.double()
+    pde64 = make_ref_pde(pde)
+    model64.zero_grad()
+    r64 = pde64.compute_residual(model64, x.double(), t.double())
+    L64 = pde64._apply_loss_fn(r64)
+    L64.backward()
+    g64 = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in model64.named_parameters()}
+    u64 = model64(inp.double()).detach()
+
+    flat = lambda g: torch.cat([g[k].flatten() for k in names]).numpy()  # noqa: E731
+    arrays = {
+        "x": x.numpy(), "t": t.numpy(), "u": u_ref.numpy(), "u64": u64.numpy(),
+        "residual": r_ref.detach().numpy(), "residual64": r64.detach().numpy(),
+        "loss": np.float32(L_ref.item()), "loss64": np.float64(L64.item()),
+        "grad": flat(g_ref), "grad64": flat(g64),
+    }
+    arrays.update(jets)
+    for k, v in sd_ref.items():
+        arrays["sd::" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **arrays)
+    manifest[tag] = {
+        "seed": seed,
+        "n_points": int(x.shape[0]),
+        "arch": {k: getattr(spec, k) for k in spec.__dataclass_fields__},
+        "pde": {"name": pde.name, "dimension": pde.dimension, "domain": [list(d) for d in pde.domain],
+                "time_domain": list(pde.time_domain), "parameters": pde.parameters,
+                "boundary_conditions": pde.boundary_conditions, "initial_condition": pde.initial_condition},
+        "param_names": names,
+        "fp32_vs_fp64": {"residual": rel_l2(r_ref.detach(), r64.detach()), "grad": rel_l2(torch.from_numpy(arrays["grad"]), torch.from_numpy(arrays["grad64"]))},
+        "oracle_vs_reference": {"residual": e_r, "loss": e_L, "grad": e_g},
+    }
+    print(f"{tag:38s} N={x.shape[0]:4d} params={sum(v.numel() for v in g_ref.values()):7d} "
+          f"oracle-vs-ref r={e_r:.1e} g={e_g:.1e} | fp32-vs-fp64 r={manifest[tag]['fp32_vs_fp64']['residual']:.1e} "
+          f"g={manifest[tag]['fp32_vs_fp64']['grad']:.1e}")
+
+
+def quirk_witnesses(manifest: dict):
+    """The behavioural quirks of SURVEY §0.3/§0.4, pinned as data."""
+    w = {}
+    pde = pde_spec("heat")
+    ref = make_ref_pde(pde)
+    torch.manual_seed(7)
+    x, t = ref.generate_collocation_points(5000, strategy="uniform")
+    w["sample_uniform_5000_shape"] = list(x.shape)
+    for n in (50000, 100000, 200000):
+        w[f"sample_uniform_{n}_rows"] = int(np.sqrt(n)) ** 2
+    torch.manual_seed(7)
+    spec = O.ArchSpec(architecture="feedforward", hidden_dim=16, num_layers=2)
+    model = make_ref_model(spec)
+    d = ref.compute_derivatives(model, x[:64], t[:64], temporal_derivatives=[1], spatial_derivatives=[2])
+    d12 = ref.compute_derivatives(model, x[:64], t[:64], temporal_derivatives=[1], spatial_derivatives=[1, 2])
+    w["heat_dx2_equals_first_derivative"] = bool(torch.equal(d["dx2"], d12["dx"]))
+    ch = pde_spec("cahn_hilliard", dimension=2)
+    refch = make_ref_pde(ch)
+    spec3 = O.ArchSpec(architecture="feedforward", hidden_dim=16, num_layers=2, input_dim=3)
+    torch.manual_seed(7)
+    m3 = make_ref_model(spec3)
+    xx, tt = refch.generate_collocation_points(64, strategy="uniform")
+    r = refch.compute_residual(m3, xx, tt)
+    dd = refch.compute_derivatives(m3, xx, tt, temporal_derivatives=[1], spatial_derivatives=[])
+    w["cahn_hilliard_2d_residual_is_u_t"] = bool(torch.equal(r.detach(), dd["dt"].detach()))
+    manifest["_quirks"] = w
+    print("quirks:", w)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    manifest: dict = {}
+    A = O.ArchSpec
+    cases = [
+        ("burgers_fourier_4x128", A("fourier", hidden_dim=128, num_layers=4), pde_spec("burgers"), 251, 0),
+        ("heat_fourier_4x128", A("fourier", hidden_dim=128, num_layers=4), pde_spec("heat"), 251, 10),
+        ("burgers_fourier_3x32", A("fourier", hidden_dim=32, num_layers=3, mapping_size=16, scale=4.0), pde_spec("burgers"), 123, 1),
+        ("burgers_feedforward_3x32", A("feedforward", hidden_dim=32, num_layers=3), pde_spec("burgers"), 123, 2),
+        ("burgers_feedforward_4x128", A("feedforward", hidden_dim=128, num_layers=4), pde_spec("burgers"), 251, 12),
+        ("heat_feedforward_gelu_3x64", A("feedforward", hidden_dim=64, num_layers=3, activation="gelu"), pde_spec("heat"), 123, 3),
+        ("allen_cahn_feedforward_sigmoid_3x32", A("feedforward", hidden_dim=32, num_layers=3, activation="sigmoid"), pde_spec("allen_cahn"), 123, 4),
+        ("kdv_siren_3x32", A("siren", hidden_dim=32, num_layers=3, omega_0=30.0), pde_spec("kdv"), 123, 5),
+        ("kdv_siren_4x128", A("siren", hidden_dim=128, num_layers=4, omega_0=30.0), pde_spec("kdv"), 251, 15),
+        ("allen_cahn_resnet_2x32", A("resnet", hidden_dim=32, num_layers=2, num_blocks=2), pde_spec("allen_cahn"), 123, 6),
+        ("allen_cahn_resnet_3x128", A("resnet", hidden_dim=128, num_layers=3, num_blocks=3), pde_spec("allen_cahn"), 251, 16),
+        ("cahn_hilliard2d_attention_2x32", A("attention", input_dim=3, hidden_dim=32, num_layers=2, activation="gelu"), pde_spec("cahn_hilliard", 2), 120, 7),
+        ("cahn_hilliard1d_feedforward_3x32", A("feedforward", hidden_dim=32, num_layers=3), pde_spec("cahn_hilliard"), 123, 8),
+        ("wave_feedforward_3x32", A("feedforward", hidden_dim=32, num_layers=3), pde_spec("wave"), 123, 9),
+        ("convection_fourier_3x32", A("fourier", hidden_dim=32, num_layers=3), pde_spec("convection"), 123, 11),
+        ("black_scholes_feedforward_3x32", A("feedforward", hidden_dim=32, num_layers=3), pde_spec("black_scholes"), 123, 13),
+        ("pendulum_siren_3x32", A("siren", hidden_dim=32, num_layers=3, omega_0=30.0), pde_spec("pendulum"), 123, 14),
+    ]
+    for tag, spec, pde, n, seed in cases:
+        run_case(tag, spec, pde, n, seed, manifest)
+    quirk_witnesses(manifest)
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True, default=float)
+    print("wrote", len(cases), "fixtures to", OUT)
+
+
+if __name__ == "__main__":
+    main()
