@@ -1,0 +1,145 @@
+/*
+ * pinn_jet.h — C ABI of the MI355X (gfx950) PINN jet engine.
+ *
+ * The reference (pinnrl 0.3.1) has no FFI: its boundary for this path is the
+ * Python object API.  Each entry point below replaces the ATen op sequence that
+ * one reference call site generates; the Python host mirror binds them with
+ * ctypes (see INTEGRATION.md for the stub a pinnrl maintainer would add).
+ *
+ *   pinn_jet_forward         <- PINNModel.forward (pinnrl/neural_networks/__init__.py:144-154)
+ *                               + PDEBase.compute_derivatives (pinnrl/pdes/pde_base.py:590-794):
+ *                               u and its input derivatives ("jets") in one launch.
+ *   pinn_jet_backward        <- loss.backward() through that graph (pinnrl/training/trainer.py:689):
+ *                               d(sum_s <cotangent_s, jet_s>)/d(theta), accumulated into weight_grads.
+ *   pinn_residual_forward    <- XxxEquation.compute_residual (pinnrl/pdes/burgers_equation.py:40-75,
+ *                               heat_equation.py:54-110, allen_cahn.py:39-111, kdv_equation.py:38-92,
+ *                               cahn_hilliard.py:39-160, wave_equation.py:38-119,
+ *                               convection_equation.py:43-78, black_scholes.py:44-93,
+ *                               pendulum_equation.py:51-94) + PDEBase._apply_loss_fn
+ *                               (pde_base.py:309-326) as a fused per-point epilogue.
+ *   pinn_residual_loss_grad  <- the metric's unit of work: compute_residual -> mean loss -> backward,
+ *                               one launch (pde_base.py:1098-1099 + trainer.py:689).
+ *
+ * Conventions: fp32, contiguous.  x:(N,dim) row-major, t:(N,1); the network input is
+ * cat([x,t],1) — spatial columns first, time LAST (pde_base.py:640).  All pointers are
+ * device pointers owned by the caller (PyTorch); the library never allocates, frees or
+ * retains device memory and launches on the stream it is given without synchronising.
+ * Return value: 0 = ok, negative = PinnStatus; pinn_last_error() describes the failure
+ * (thread-local).  `weights` / `weight_grads` follow the reference's state_dict order
+ * for the architecture (buffers included, e.g. fourier: B, W0, b0, ..., W_out, b_out);
+ * a NULL entry in weight_grads skips that tensor.
+ */
+#ifndef PINN_JET_H
+#define PINN_JET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PINN_ABI_VERSION 1
+#define PINN_MAX_LINEAR 24
+#define PINN_MAX_STREAMS 7 /* value + up to 2 time + up to 4 space derivatives */
+
+typedef enum PinnStatus {
+  PINN_OK = 0,
+  PINN_ERR_BAD_DESC = -1,
+  PINN_ERR_UNSUPPORTED = -2,
+  PINN_ERR_MISALIGNED = -3,
+  PINN_ERR_WORKSPACE = -4,
+  PINN_ERR_HIP = -5,
+  PINN_ERR_BAD_ORDER = -6
+} PinnStatus;
+
+typedef enum PinnArch {
+  PINN_ARCH_FEEDFORWARD = 0, /* feedforward.py:9-73 (layer_norm = False) */
+  PINN_ARCH_FOURIER = 1,     /* fourier.py:65-124 */
+  PINN_ARCH_SIREN = 2,       /* siren.py:49-90 */
+  PINN_ARCH_RESNET = 3,      /* resnet.py:68-142 */
+  PINN_ARCH_ATTENTION = 4    /* attention.py:110-183 (sequence length 1 => an MLP with LayerNorm) */
+} PinnArch;
+
+typedef enum PinnAct { /* base_network.py:91-104, plus SIREN's sin(omega_0 z) */
+  PINN_ACT_TANH = 0,
+  PINN_ACT_SIN = 1,
+  PINN_ACT_GELU = 2,
+  PINN_ACT_SIGMOID = 3,
+  PINN_ACT_RELU = 4,
+  PINN_ACT_LEAKY_RELU = 5,
+  PINN_ACT_IDENTITY = 6
+} PinnAct;
+
+typedef enum PinnPde { /* as-reference residuals; see DESIGN.md for the quirks kept */
+  PINN_PDE_BURGERS = 0,       /* u_t + u u_x - c0 u_xx              c0 = nu        */
+  PINN_PDE_HEAT = 1,          /* u_t - c0 u_x   (reference: "dx2" is a FIRST derivative) */
+  PINN_PDE_ALLEN_CAHN = 2,    /* u_t - c0^2 u_xx - u + u^3          c0 = epsilon   */
+  PINN_PDE_KDV = 3,           /* u_t + 6 u u_x + u_xxx                             */
+  PINN_PDE_CAHN_HILLIARD = 4, /* u_t - d_xx(-c0^2 u_xx + c^3 - c), c = clamp(u,+-10) */
+  PINN_PDE_WAVE = 5,          /* u_tt - c0^2 u_xx                                  */
+  PINN_PDE_CONVECTION = 6,    /* u_t + c0 u_x                                      */
+  PINN_PDE_BLACK_SCHOLES = 7, /* u_t + .5 c0^2 x^2 u_xx + c1 x u_x - c1 u  (sigma, r) */
+  PINN_PDE_PENDULUM = 8,      /* u_tt + c0 sin(u)                   c0 = g/L       */
+  PINN_PDE_HEAT_LAPLACIAN = 9 /* u_t - c0 u_xx  (the intended heat equation; never the parity path) */
+} PinnPde;
+
+typedef enum PinnLoss { PINN_LOSS_MSE = 0, PINN_LOSS_MAE = 1, PINN_LOSS_HUBER = 2 } PinnLoss;
+
+typedef struct PinnNetDesc {
+  int32_t arch;                    /* PinnArch */
+  int32_t activation;              /* PinnAct of the hidden layers */
+  int32_t input_dim;               /* spatial dimension + 1 */
+  int32_t num_linear;              /* Linear layers including the output layer */
+  int32_t widths[PINN_MAX_LINEAR]; /* out_features of each Linear; widths[num_linear-1] must be 1 */
+  int32_t mapping_size;            /* fourier: columns of B (features = 2 * mapping_size) */
+  float act_param;                 /* omega_0 for PINN_ACT_SIN */
+  float ln_eps;                    /* LayerNorm epsilon (resnet / attention) */
+  int32_t num_blocks;              /* resnet blocks / attention layers */
+  int32_t flags;                   /* reserved, 0 */
+} PinnNetDesc;
+
+typedef struct PinnPdeDesc {
+  int32_t kind;      /* PinnPde */
+  int32_t dimension; /* spatial dimension; >= 2 keeps only the terms the reference keeps */
+  int32_t loss;      /* PinnLoss */
+  float coef[4];
+  float huber_delta;
+} PinnPdeDesc;
+
+int pinn_abi_version(void);
+const char* pinn_last_error(void);
+
+/* (time_order, space_order) of the jet streams a PDE's residual consumes; K = 1 + nt + nx. */
+int pinn_pde_streams(const PinnPdeDesc* pde, int32_t* time_order, int32_t* space_order);
+
+/* Bytes of scratch the backward entry points need for N points (0 for forward-only calls). */
+size_t pinn_workspace_bytes(const PinnNetDesc* net, int64_t N, int32_t time_order, int32_t space_order);
+
+/* jets_out[s] : N floats each, stream order [u, d/dt.., d/dx..]; all K = 1+nt+nx entries required. */
+int pinn_jet_forward(const PinnNetDesc* net, const float* const* weights, const float* x, const float* t,
+                     int64_t N, int32_t time_order, int32_t space_order, float* const* jets_out, void* stream);
+
+/* Recomputes the forward per tile (tape in `workspace`), then accumulates
+ * d(sum_s sum_n jet_cotangents[s][n] * jet_s[n]) / d(weights) into weight_grads (+=). */
+int pinn_jet_backward(const PinnNetDesc* net, const float* const* weights, const float* x, const float* t,
+                      int64_t N, int32_t time_order, int32_t space_order, const float* const* jet_cotangents,
+                      float* const* weight_grads, void* workspace, size_t ws_bytes, void* stream);
+
+/* residual_out: N floats or NULL.  loss_sum_out: 1 float or NULL; receives += sum_n l(r_n)
+ * (l = r^2 | |r| | huber), i.e. the UNnormalised loss — the caller divides by the global N. */
+int pinn_residual_forward(const PinnNetDesc* net, const float* const* weights, const PinnPdeDesc* pde,
+                          const float* x, const float* t, int64_t N, float* residual_out, float* loss_sum_out,
+                          void* stream);
+
+/* One launch: residual, loss sum, and weight_grads += grad_scale * d(sum_n l(r_n))/d(weights).
+ * For mean-squared loss over N_total points use grad_scale = upstream / N_total. */
+int pinn_residual_loss_grad(const PinnNetDesc* net, const float* const* weights, const PinnPdeDesc* pde,
+                            const float* x, const float* t, int64_t N, float grad_scale, float* residual_out,
+                            float* loss_sum_out, float* const* weight_grads, void* workspace, size_t ws_bytes,
+                            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINN_JET_H */

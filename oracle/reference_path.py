@@ -299,6 +299,7 @@ def compute_derivatives(
             g = _grad(u if i == 1 else prev, t)
             if g is None:
                 g = torch.zeros_like(u)
+            g = g.requires_grad_(True)  # pde_base.py:671,688 (turns a zeros fallback into a leaf)
             d["dt" if i == 1 else f"dt{i}"] = g
             prev = g
     if spatial_derivatives:
@@ -310,6 +311,7 @@ def compute_derivatives(
                 g = _grad(u if i == 1 else prev, x)
                 if g is None:
                     g = torch.zeros_like(u)
+                g = g.requires_grad_(True)  # pde_base.py:713,731
                 d["dx" if i == 1 else f"dx{i}"] = g
                 prev = g
         else:  # pde_base.py:733-779 — gradient w.r.t. a fresh slice is unused -> zeros
@@ -323,6 +325,7 @@ def compute_derivatives(
                         g = _grad(u if i == 1 else prev, x[:, dim : dim + 1])
                         if g is None:
                             g = torch.zeros_like(u)
+                        g = g.requires_grad_(True)  # pde_base.py:756,776
                         d[f"d{name * i}"] = g
                         prev = g
     if spatial_derivatives and 2 in spatial_derivatives:  # pde_base.py:781-792

@@ -1,0 +1,293 @@
+"""Tensor-level front end of the HIP jet engine.
+
+`NetProgram` describes one network as the C ABI wants it (descriptor + the live
+parameter tensors in `state_dict` order); the functions below launch the fused
+kernels on the current HIP stream with raw device pointers, and the two
+`autograd.Function`s splice them into PyTorch graphs so that the reference's
+call pattern (`residual = pde.compute_residual(...)`, `loss.backward()`,
+`optimizer.step()`) keeps working unchanged.
+
+Everything here requires a ROCm device and the compiled library; nothing falls
+back to eager PyTorch.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+
+
+def _require_device(*tensors: Tensor) -> torch.device:
+    dev = None
+    for x in tensors:
+        if x is None:
+            continue
+        if not x.is_cuda:
+            raise RuntimeError(
+                "pinnrl_amd: the HIP jet engine only runs on a ROCm device (got a CPU tensor); there is no CPU fallback"
+            )
+        dev = dev or x.device
+        if x.device != dev:
+            raise RuntimeError(f"pinnrl_amd: tensors on different devices ({x.device} vs {dev})")
+    return dev
+
+
+def _f32c(x: Tensor) -> Tensor:
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x if x.is_contiguous() else x.contiguous()
+
+
+class NetProgram:
+    """One network in the form the C ABI consumes.
+
+    tensors: parameters AND buffers in the reference's `state_dict` order (fourier: B first).
+    trainable[i] is False for buffers (no gradient slot).
+    """
+
+    def __init__(self, arch: str, activation: str, input_dim: int, widths: Sequence[int], tensors: Sequence[Tensor],
+                 trainable: Sequence[bool], mapping_size: int = 0, omega_0: float = 0.0, ln_eps: float = 1e-5,
+                 num_blocks: int = 0):
+        if arch not in _lib.ARCH:
+            raise NotImplementedError(f"pinnrl_amd: architecture '{arch}' has no fused HIP kernel")
+        if activation not in _lib.ACT:
+            raise ValueError(f"Unsupported activation: {activation}")  # base_network.py:104
+        if len(widths) > _lib.PINN_MAX_LINEAR:
+            raise NotImplementedError(f"pinnrl_amd: more than {_lib.PINN_MAX_LINEAR} Linear layers")
+        d = _lib.PinnNetDesc()
+        d.arch = _lib.ARCH[arch]
+        d.activation = _lib.ACT[activation]
+        d.input_dim = int(input_dim)
+        d.num_linear = len(widths)
+        for i, w in enumerate(widths):
+            d.widths[i] = int(w)
+        d.mapping_size = int(mapping_size)
+        d.act_param = float(omega_0)
+        d.ln_eps = float(ln_eps)
+        d.num_blocks = int(num_blocks)
+        self.desc = d
+        self.arch = arch
+        self.tensors = list(tensors)
+        self.trainable = list(trainable)
+        self.input_dim = int(input_dim)
+
+    # -- pointer tables ---------------------------------------------------------------------
+    def _weight_ptrs(self):
+        for p in self.tensors:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("pinnrl_amd: parameters must be contiguous float32")
+        return (ctypes.c_void_p * len(self.tensors))(*[p.data_ptr() for p in self.tensors])
+
+    def grad_layout(self) -> Tuple[List[int], int]:
+        """Offsets (in floats, 16-byte aligned) of every trainable tensor inside one flat gradient buffer."""
+        offs, n = [], 0
+        for p, tr in zip(self.tensors, self.trainable):
+            offs.append(n if tr else -1)
+            if tr:
+                n += (p.numel() + 3) // 4 * 4
+        return offs, n
+
+    def flops_per_point(self) -> int:
+        """F_fwd = 2 * sum(in*out) over Linear layers (+ the Fourier projection) — SURVEY.md §8(d)."""
+        d = self.desc
+        widths = [d.widths[i] for i in range(d.num_linear)]
+        if self.arch == "fourier":
+            prev, total = 2 * d.mapping_size, 2 * d.input_dim * d.mapping_size
+        else:
+            prev, total = d.input_dim, 0
+        for w in widths:
+            total += 2 * prev * w
+            prev = w
+        return total
+
+
+_workspaces: Dict[torch.device, Tensor] = {}
+
+
+def _workspace(dev: torch.device, nbytes: int) -> Tensor:
+    """Reusable scratch owned by PyTorch's caching allocator (the library never allocates)."""
+    ws = _workspaces.get(dev)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _workspaces[dev] = ws
+    return ws
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _prep_points(prog: NetProgram, x: Tensor, t: Tensor) -> Tuple[Tensor, Tensor, int]:
+    x, t = _f32c(x.detach()), _f32c(t.detach())
+    if x.dim() != 2 or t.dim() != 2 or t.shape[1] != 1 or x.shape[0] != t.shape[0]:
+        raise ValueError(f"expected x:(N,dim), t:(N,1); got {tuple(x.shape)}, {tuple(t.shape)}")
+    if x.shape[1] + 1 != prog.input_dim:
+        raise ValueError(f"model input_dim={prog.input_dim} but cat([x,t]) has {x.shape[1] + 1} columns")
+    return x, t, x.shape[0]
+
+
+def pde_desc(kind: str, dimension: int = 1, coef: Sequence[float] = (), loss: str = "mse", huber_delta: float = 1.0):
+    d = _lib.PinnPdeDesc()
+    d.kind = _lib.PDE[kind]
+    d.dimension = int(dimension)
+    d.loss = _lib.LOSS.get(loss, 0)  # unknown names fall back to mse (pde_base.py:313-315)
+    for i, c in enumerate(coef):
+        d.coef[i] = float(c)
+    d.huber_delta = float(huber_delta)
+    return d
+
+
+def pde_streams(pd) -> Tuple[int, int]:
+    nt, nx = ctypes.c_int32(), ctypes.c_int32()
+    _lib.check(_lib.load().pinn_pde_streams(ctypes.byref(pd), ctypes.byref(nt), ctypes.byref(nx)))
+    return nt.value, nx.value
+
+
+# ---------------------------------------------------------------------------------------------
+# raw launches
+# ---------------------------------------------------------------------------------------------
+def jets_forward(prog: NetProgram, x: Tensor, t: Tensor, nt: int, nx: int) -> Tensor:
+    """(K, N) tensor of [u, d/dt.., d/dx..] — one launch, no graph."""
+    lib = _lib.load()
+    dev = _require_device(x, t, *prog.tensors)
+    x, t, N = _prep_points(prog, x, t)
+    K = 1 + nt + nx
+    out = torch.empty((K, N), dtype=torch.float32, device=dev)
+    if N == 0:
+        return out
+    optr = (ctypes.c_void_p * K)(*[out[s].data_ptr() for s in range(K)])
+    with torch.cuda.device(dev):
+        _lib.check(lib.pinn_jet_forward(ctypes.byref(prog.desc), prog._weight_ptrs(), x.data_ptr(), t.data_ptr(), N,
+                                        nt, nx, optr, _stream(dev)))
+    return out
+
+
+def _grad_ptrs(prog: NetProgram, flat: Tensor):
+    offs, _ = prog.grad_layout()
+    base = flat.data_ptr()
+    return (ctypes.c_void_p * len(offs))(*[(base + 4 * o) if o >= 0 else None for o in offs])
+
+
+def new_flat_grad(prog: NetProgram, dev: torch.device) -> Tensor:
+    _, n = prog.grad_layout()
+    return torch.zeros(n, dtype=torch.float32, device=dev)
+
+
+def split_flat_grad(prog: NetProgram, flat: Tensor) -> List[Optional[Tensor]]:
+    offs, _ = prog.grad_layout()
+    return [flat[o : o + p.numel()].view_as(p) if o >= 0 else None for o, p in zip(offs, prog.tensors)]
+
+
+def jets_backward(prog: NetProgram, x: Tensor, t: Tensor, nt: int, nx: int, cot: Tensor, flat_grad: Tensor) -> None:
+    """flat_grad += d<cot, jets>/d(theta).  cot: (K, N)."""
+    lib = _lib.load()
+    dev = _require_device(x, t, cot, flat_grad, *prog.tensors)
+    x, t, N = _prep_points(prog, x, t)
+    if N == 0:
+        return
+    K = 1 + nt + nx
+    cot = _f32c(cot)
+    assert cot.shape == (K, N)
+    cptr = (ctypes.c_void_p * K)(*[cot[s].data_ptr() for s in range(K)])
+    nbytes = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), N, nt, nx)
+    ws = _workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pinn_jet_backward(ctypes.byref(prog.desc), prog._weight_ptrs(), x.data_ptr(), t.data_ptr(), N, nt,
+                                         nx, cptr, _grad_ptrs(prog, flat_grad), ws.data_ptr(), ws.numel(), _stream(dev)))
+
+
+def residual_forward(prog: NetProgram, pd, x: Tensor, t: Tensor, want_residual: bool = True) -> Tuple[Optional[Tensor], Tensor]:
+    """(residual (N,1) | None, loss_sum (1,)) with loss_sum = sum_n l(r_n) over THESE points."""
+    lib = _lib.load()
+    dev = _require_device(x, t, *prog.tensors)
+    x, t, N = _prep_points(prog, x, t)
+    r = torch.empty((N, 1), dtype=torch.float32, device=dev) if want_residual else None
+    s = torch.zeros(1, dtype=torch.float32, device=dev)
+    if N:
+        with torch.cuda.device(dev):
+            _lib.check(lib.pinn_residual_forward(ctypes.byref(prog.desc), prog._weight_ptrs(), ctypes.byref(pd),
+                                                 x.data_ptr(), t.data_ptr(), N, r.data_ptr() if want_residual else None,
+                                                 s.data_ptr(), _stream(dev)))
+    return r, s
+
+
+def residual_loss_grad(prog: NetProgram, pd, x: Tensor, t: Tensor, grad_scale: float, flat_grad: Tensor,
+                       want_residual: bool = False, loss_sum: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Tensor]:
+    """One launch: flat_grad += grad_scale * d(sum_n l(r_n))/d(theta); returns (residual | None, loss_sum)."""
+    lib = _lib.load()
+    dev = _require_device(x, t, flat_grad, *prog.tensors)
+    x, t, N = _prep_points(prog, x, t)
+    r = torch.empty((N, 1), dtype=torch.float32, device=dev) if want_residual else None
+    s = loss_sum if loss_sum is not None else torch.zeros(1, dtype=torch.float32, device=dev)
+    if N:
+        nt, nx = pde_streams(pd)
+        nbytes = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), N, nt, nx)
+        ws = _workspace(dev, nbytes)
+        with torch.cuda.device(dev):
+            _lib.check(lib.pinn_residual_loss_grad(ctypes.byref(prog.desc), prog._weight_ptrs(), ctypes.byref(pd),
+                                                   x.data_ptr(), t.data_ptr(), N, float(grad_scale),
+                                                   r.data_ptr() if want_residual else None, s.data_ptr(),
+                                                   _grad_ptrs(prog, flat_grad), ws.data_ptr(), ws.numel(), _stream(dev)))
+    return r, s
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd splices
+# ---------------------------------------------------------------------------------------------
+class JetFunction(torch.autograd.Function):
+    """jets = f(theta; x, t), differentiable w.r.t. the trainable tensors of the program.
+
+    Replaces `u = model(cat[x,t])` + the chained `autograd.grad(create_graph=True)` calls of
+    `PDEBase.compute_derivatives` (pinnrl/pdes/pde_base.py:640-732).  The coordinates are treated
+    as constants, as the reference does after its `detach()` (pde_base.py:630-631).
+    """
+
+    @staticmethod
+    def forward(ctx, prog: NetProgram, x: Tensor, t: Tensor, nt: int, nx: int, *params: Tensor):
+        ctx.prog, ctx.nt, ctx.nx = prog, nt, nx
+        ctx.save_for_backward(x, t)
+        return jets_forward(prog, x, t, nt, nx)
+
+    @staticmethod
+    def backward(ctx, cot: Tensor):
+        prog = ctx.prog
+        x, t = ctx.saved_tensors
+        flat = new_flat_grad(prog, cot.device)
+        jets_backward(prog, x, t, ctx.nt, ctx.nx, cot, flat)
+        grads = split_flat_grad(prog, flat)
+        return (None, None, None, None, None, *grads)
+
+
+class ResidualLossFunction(torch.autograd.Function):
+    """mean_n l(r_n) with the gradient produced by the SAME launch (fused forward + reverse sweep).
+
+    Replaces `residual = compute_residual(...)`, `_apply_loss_fn(residual)` and the residual branch of
+    `loss.backward()` (pde_base.py:1098-1099, trainer.py:689).  `n_total` is the global point count
+    when the batch is sharded over ranks (the local sum is divided by it).
+    """
+
+    @staticmethod
+    def forward(ctx, prog: NetProgram, pd, x: Tensor, t: Tensor, n_total: int, *params: Tensor):
+        need_grad = any(p.requires_grad for p in params)
+        dev = x.device
+        if need_grad:
+            flat = new_flat_grad(prog, dev)
+            _, s = residual_loss_grad(prog, pd, x, t, 1.0 / float(n_total), flat)
+            ctx.flat, ctx.prog = flat, prog
+        else:
+            _, s = residual_forward(prog, pd, x, t, want_residual=False)
+            ctx.flat, ctx.prog = None, prog
+        return (s / float(n_total)).reshape(())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        if ctx.flat is None:
+            return (None,) * 5 + (None,) * len(ctx.prog.tensors)
+        grads = split_flat_grad(ctx.prog, ctx.flat * g)
+        return (None, None, None, None, None, *grads)

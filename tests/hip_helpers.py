@@ -1,0 +1,43 @@
+"""Test helpers: golden fixture -> NetProgram on the GPU, oracle comparisons."""
+
+import torch
+
+import pinnrl_amd  # noqa: F401
+from pinnrl_amd import engine as E
+
+FUSED_ARCHS = ("fourier", "feedforward", "siren")
+
+
+def program_from_spec(spec, sd, device):
+    """Build the C-ABI program from an oracle ArchSpec + state_dict (state_dict order = ABI order)."""
+    tensors = [v.to(device).contiguous() for v in sd.values()]
+    names = list(sd.keys())
+    trainable = [not n.endswith("fourier.B") for n in names]
+    if spec.architecture == "fourier":
+        widths = [spec.hidden_dim] * (spec.num_layers - 1) + [spec.output_dim]
+        return E.NetProgram("fourier", spec.activation, spec.input_dim, widths, tensors, trainable,
+                            mapping_size=spec.mapping_size), names
+    if spec.architecture == "feedforward":
+        widths = list(spec.dims()) + [spec.output_dim]
+        return E.NetProgram("feedforward", spec.activation, spec.input_dim, widths, tensors, trainable), names
+    if spec.architecture == "siren":
+        widths = list(spec.dims()) + [spec.output_dim]
+        return E.NetProgram("siren", "sin", spec.input_dim, widths, tensors, trainable, omega_0=spec.omega_0), names
+    raise NotImplementedError(spec.architecture)
+
+
+def pde_desc_from_spec(pde):
+    p = pde.parameters
+    name = pde.name
+    coef = {
+        "burgers": [p.get("nu", 0.01)],
+        "heat": [p.get("alpha", 0.0)],
+        "allen_cahn": [p.get("epsilon", 0.1)],
+        "kdv": [],
+        "cahn_hilliard": [p.get("epsilon", 0.1)],
+        "wave": [p.get("c", 1.0)],
+        "convection": [(p.get("velocity", [1.0]) or [1.0])[0]],
+        "black_scholes": [p.get("sigma", 0.2), p.get("r", 0.05)],
+        "pendulum": [p.get("g", 9.81) / p.get("L", 1.0)],
+    }[name]
+    return E.pde_desc(name, pde.dimension, coef, pde.loss_function, pde.huber_delta)
