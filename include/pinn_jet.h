@@ -17,6 +17,7 @@
  *                               convection_equation.py:43-78, black_scholes.py:44-93,
  *                               pendulum_equation.py:51-94) + PDEBase._apply_loss_fn
  *                               (pde_base.py:309-326) as a fused per-point epilogue.
+ *   pinn_residual_backward   <- loss.backward() through a residual tensor (trainer.py:689, :607-626).
  *   pinn_residual_loss_grad  <- the metric's unit of work: compute_residual -> mean loss -> backward,
  *                               one launch (pde_base.py:1098-1099 + trainer.py:689).
  *
@@ -138,6 +139,13 @@ int pinn_residual_loss_grad(const PinnNetDesc* net, const float* const* weights,
                             const float* x, const float* t, int64_t N, float grad_scale, float* residual_out,
                             float* loss_sum_out, float* const* weight_grads, void* workspace, size_t ws_bytes,
                             void* stream);
+
+/* weight_grads += d(sum_n residual_cotangent[n] * r_n)/d(weights): the backward of pinn_residual_forward for an
+ * arbitrary downstream graph (loss.backward() through `residual`, trainer.py:689; LRW's per-component
+ * backward passes, trainer.py:607-626). */
+int pinn_residual_backward(const PinnNetDesc* net, const float* const* weights, const PinnPdeDesc* pde,
+                           const float* x, const float* t, int64_t N, const float* residual_cotangent,
+                           float* const* weight_grads, void* workspace, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ LOSS = {"mse": 0, "mae": 1, "huber": 2}
 
 EXPORTS = (
     "pinn_abi_version", "pinn_last_error", "pinn_pde_streams", "pinn_workspace_bytes", "pinn_jet_forward",
-    "pinn_jet_backward", "pinn_residual_forward", "pinn_residual_loss_grad",
+    "pinn_jet_backward", "pinn_residual_forward", "pinn_residual_backward", "pinn_residual_loss_grad",
 )
 
 
@@ -97,6 +97,9 @@ def load():
                                           ctypes.c_size_t, vp]
         lib.pinn_residual_forward.restype = ctypes.c_int
         lib.pinn_residual_forward.argtypes = [P(PinnNetDesc), P(vp), P(PinnPdeDesc), vp, vp, i64, vp, vp, vp]
+        lib.pinn_residual_backward.restype = ctypes.c_int
+        lib.pinn_residual_backward.argtypes = [P(PinnNetDesc), P(vp), P(PinnPdeDesc), vp, vp, i64, vp, P(vp), vp,
+                                               ctypes.c_size_t, vp]
         lib.pinn_residual_loss_grad.restype = ctypes.c_int
         lib.pinn_residual_loss_grad.argtypes = [P(PinnNetDesc), P(vp), P(PinnPdeDesc), vp, vp, i64, f32, vp, vp,
                                                 P(vp), vp, ctypes.c_size_t, vp]

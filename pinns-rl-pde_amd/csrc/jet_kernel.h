@@ -84,6 +84,7 @@ struct KernelArgs {
   const float* jets_bar[PINN_MAX_STREAMS];   // MODE_JETS backward
   float* residual_out;                       // MODE_PDE, nullable
   float* loss_sum;                           // MODE_PDE, nullable
+  const float* res_bar;                      // MODE_PDE backward, nullable: external cotangent of r (N floats)
   float* tape;                               // BWD workspace
   long long tape_stride;                     // floats per workgroup
 };
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void jet_kernel(const KernelArgs a) {
           if (tid == 0) atomicAdd(a.loss_sum, sacc);
         }
         if constexpr (BWD) {
-          const float rb = a.grad_scale * dl;
+          const float rb = a.res_bar ? (ok ? a.res_bar[p] : 0.0f) : a.grad_scale * dl;
 #pragma unroll
           for (int s = 0; s < K; ++s) UB[s * kT + tid] = rb * d[s];
         }

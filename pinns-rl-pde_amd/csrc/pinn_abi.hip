@@ -161,7 +161,7 @@ static int grid_for(const NetDev& n, int K, long long N, bool bwd, size_t* lds_o
 static int run(const PinnNetDesc* net, const float* const* weights, float* const* grads, const PinnPdeDesc* pde,
                const float* x, const float* t, int64_t N, int nt, int nx, int mode, float grad_scale,
                float* const* jets_out, const float* const* jets_bar, float* residual_out, float* loss_sum,
-               void* workspace, size_t ws_bytes, bool bwd, void* stream) {
+               void* workspace, size_t ws_bytes, bool bwd, void* stream, const float* res_bar = nullptr) {
   if (N <= 0) return PINN_OK;
   if (!x && net && net->input_dim > 1) return fail(PINN_ERR_BAD_DESC, "x is null");
   if (!t) return fail(PINN_ERR_BAD_DESC, "t is null");
@@ -199,6 +199,7 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
   }
   a.residual_out = residual_out;
   a.loss_sum = loss_sum;
+  a.res_bar = res_bar;
   if (bwd) {
     const int ntile = a.net.hmax > 128 ? 2 : 1;
     a.tape_stride = jet_tape_floats_per_wg(K, a.net.n_layers, ntile);
@@ -292,6 +293,17 @@ int pinn_residual_loss_grad(const PinnNetDesc* net, const float* const* weights,
   if (rc) return rc;
   return run(net, weights, weight_grads, pde, x, t, N, nt, nx, MODE_PDE, grad_scale, nullptr, nullptr, residual_out,
              loss_sum_out, workspace, ws_bytes, true, stream);
+}
+
+int pinn_residual_backward(const PinnNetDesc* net, const float* const* weights, const PinnPdeDesc* pde, const float* x,
+                           const float* t, int64_t N, const float* residual_cotangent, float* const* weight_grads,
+                           void* workspace, size_t ws_bytes, void* stream) {
+  if (!weight_grads || !residual_cotangent) return fail(PINN_ERR_BAD_DESC, "null cotangent or weight_grads");
+  int32_t nt, nx;
+  int rc = pinn_pde_streams(pde, &nt, &nx);
+  if (rc) return rc;
+  return run(net, weights, weight_grads, pde, x, t, N, nt, nx, MODE_PDE, 0.0f, nullptr, nullptr, nullptr, nullptr,
+             workspace, ws_bytes, true, stream, residual_cotangent);
 }
 
 }  // extern "C"

@@ -237,6 +237,24 @@ def residual_loss_grad(prog: NetProgram, pd, x: Tensor, t: Tensor, grad_scale: f
     return r, s
 
 
+def residual_backward(prog: NetProgram, pd, x: Tensor, t: Tensor, res_bar: Tensor, flat_grad: Tensor) -> None:
+    """flat_grad += d<res_bar, r>/d(theta) (forward recomputed per tile inside the launch)."""
+    lib = _lib.load()
+    dev = _require_device(x, t, res_bar, flat_grad, *prog.tensors)
+    x, t, N = _prep_points(prog, x, t)
+    if N == 0:
+        return
+    res_bar = _f32c(res_bar).reshape(-1)
+    assert res_bar.numel() == N
+    nt, nx = pde_streams(pd)
+    nbytes = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), N, nt, nx)
+    ws = _workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pinn_residual_backward(ctypes.byref(prog.desc), prog._weight_ptrs(), ctypes.byref(pd), x.data_ptr(),
+                                              t.data_ptr(), N, res_bar.data_ptr(), _grad_ptrs(prog, flat_grad),
+                                              ws.data_ptr(), ws.numel(), _stream(dev)))
+
+
 # ---------------------------------------------------------------------------------------------
 # autograd splices
 # ---------------------------------------------------------------------------------------------
@@ -264,6 +282,24 @@ class JetFunction(torch.autograd.Function):
         return (None, None, None, None, None, *grads)
 
 
+class ResidualFunction(torch.autograd.Function):
+    """r = residual(theta; x, t) as an (N, 1) tensor with a grad_fn — `XxxEquation.compute_residual`."""
+
+    @staticmethod
+    def forward(ctx, prog: NetProgram, pd, x: Tensor, t: Tensor, *params: Tensor):
+        ctx.prog, ctx.pd = prog, pd
+        ctx.save_for_backward(x, t)
+        r, _ = residual_forward(prog, pd, x, t, want_residual=True)
+        return r
+
+    @staticmethod
+    def backward(ctx, rbar: Tensor):
+        x, t = ctx.saved_tensors
+        flat = new_flat_grad(ctx.prog, rbar.device)
+        residual_backward(ctx.prog, ctx.pd, x, t, rbar, flat)
+        return (None, None, None, None, *split_flat_grad(ctx.prog, flat))
+
+
 class ResidualLossFunction(torch.autograd.Function):
     """mean_n l(r_n) with the gradient produced by the SAME launch (fused forward + reverse sweep).
 
@@ -274,7 +310,7 @@ class ResidualLossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, prog: NetProgram, pd, x: Tensor, t: Tensor, n_total: int, *params: Tensor):
-        need_grad = any(p.requires_grad for p in params)
+        need_grad = any(ctx.needs_input_grad[5:])  # grad mode is off inside forward(); this reflects the caller's
         dev = x.device
         if need_grad:
             flat = new_flat_grad(prog, dev)

@@ -1,0 +1,474 @@
+"""The nine PDE classes of pinnrl/pdes/*.py on top of the fused jet engine.
+
+Each class keeps the reference's name, constructor, parameter properties, initial-condition
+factory and exact solution (caller-side helpers), and declares its residual to the engine as
+(`KIND`, coefficients): the fused PDE epilogue in csrc/jet_device.h evaluates it per point, with
+the reference's behaviour INCLUDING its quirks (heat differentiates once, >= 2-D residuals lose
+their spatial terms — SURVEY.md §0.3).  `_residual_from_jets` is the same formula as torch ops on
+the kernel's jets; it is only used in inverse mode, where a coefficient is an `nn.Parameter` and
+must stay in the autograd graph.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Dict
+
+import torch
+
+from .pde_base import PDEBase, PDEConfig
+
+
+def _as_float(v):
+    return float(v.detach()) if isinstance(v, torch.Tensor) else float(v)
+
+
+class BurgersEquation(PDEBase):
+    """u_t + u u_x - nu u_xx  (burgers_equation.py:40-75)."""
+
+    KIND = "burgers"
+
+    def __init__(self, config: PDEConfig, **kwargs):
+        super().__init__(config)
+
+    @property
+    def nu(self):
+        return self.get_parameter("nu", default=0.01)  # note: the YAML key `viscosity` is ignored upstream too
+
+    def _coefficients(self):
+        return (self.nu,)
+
+    def _residual_from_jets(self, j, x, nt, nx):
+        if self.dimension > 1:
+            return j[1]
+        return j[1] + j[0] * j[nt + 1] - self.nu * j[nt + 2]
+
+    def _create_boundary_condition(self, bc_type: str, params: Dict[str, Any]):  # burgers_equation.py:131-160
+        if bc_type == "initial":
+            kind = params.get("type", "sine")
+            if kind == "sine":
+                A, k = params.get("amplitude", -1.0), params.get("frequency", 1.0)
+                if self.dimension == 1:
+                    return lambda x, t: A * torch.sin(k * torch.pi * x)
+                return lambda x, t: A * torch.prod(torch.sin(k * torch.pi * x), dim=1, keepdim=True)
+            if kind == "tanh":
+                eps = params.get("epsilon", 0.1)
+                if self.dimension == 1:
+                    return lambda x, t: torch.tanh((x - 0.5) / eps)
+                return lambda x, t: torch.prod(torch.tanh((x - 0.5) / eps), dim=1, keepdim=True)
+            raise ValueError(f"Unsupported initial condition type: {kind}")
+        return super()._create_boundary_condition(bc_type, params)
+
+    def exact_solution(self, x, t):  # burgers_equation.py:77-129 (Cole-Hopf with phi_x in closed form)
+        if not self.config.exact_solution:
+            return None
+        kind = self.config.exact_solution.get("type", "cole_hopf")
+        nu0 = _as_float(self.nu)
+        if kind == "cole_hopf":
+            nu = self.config.exact_solution.get("viscosity", nu0)
+            k = self.config.exact_solution.get("initial_frequency", 1.0)
+            sol = torch.ones_like(x[:, 0:1])
+            for d in range(self.dimension):
+                xd = x[:, d : d + 1]
+                decay = torch.exp(-nu * (k * torch.pi) ** 2 * t)
+                phi = -torch.cos(k * torch.pi * xd) * decay
+                phi_x = k * torch.pi * torch.sin(k * torch.pi * xd) * decay
+                sol = sol * (-2 * nu * phi_x / phi)
+            return sol
+        if kind == "tanh":
+            eps = self.config.exact_solution.get("epsilon", 0.1)
+            sol = torch.ones_like(x[:, 0:1])
+            for d in range(self.dimension):
+                sol = sol * torch.tanh((x[:, d : d + 1] - 0.5 - nu0 * t) / eps)
+            return sol
+        raise ValueError(f"Unsupported exact solution type: {kind}")
+
+
+class HeatEquation(PDEBase):
+    """As-reference residual u_t - alpha * d["laplacian"], where "laplacian" is a FIRST x-derivative
+    (heat_equation.py:54-110 requests spatial_derivatives=[2] only; pde_base.py:695-732 then chains once)."""
+
+    KIND = "heat"
+
+    def __init__(self, config: PDEConfig, **kwargs):
+        super().__init__(config)
+
+    @property
+    def alpha(self):
+        return self.get_parameter("alpha", required=True)
+
+    def _coefficients(self):
+        return (self.alpha,)
+
+    def _residual_from_jets(self, j, x, nt, nx):
+        if self.dimension > 1:
+            return j[1]
+        return j[1] - self.alpha * j[nt + 1]
+
+    def _calculate_decay_rate(self, k: float):  # heat_equation.py:40-52
+        L = self.config.domain[0][1] - self.config.domain[0][0]
+        return self.alpha * (2 * torch.pi * k / L) ** 2
+
+    def _create_boundary_condition(self, bc_type: str, params: Dict[str, Any]):  # heat_equation.py:214-300
+        if bc_type == "initial":
+            kind = params.get("type", "sine")
+            A, k = params.get("amplitude", 1.0), params.get("frequency", 2.0)
+            L = self.config.domain[0][1] - self.config.domain[0][0]
+            wn = 2 * torch.pi * k / L
+            if kind == "sin_exp_decay":
+                dr = self._calculate_decay_rate(k)
+                if self.dimension == 1:
+                    return lambda x, t: A * torch.sin(wn * x) * torch.exp(-dr * t)
+
+                def ic(x, t):
+                    sol = torch.ones_like(x[:, 0:1])
+                    for d in range(self.dimension):
+                        Ld = self.config.domain[d][1] - self.config.domain[d][0]
+                        sol = sol * torch.sin(2 * torch.pi * k / Ld * x[:, d : d + 1])
+                    return A * sol * torch.exp(-dr * t)
+
+                return ic
+            if kind == "sine":
+                if self.dimension == 1:
+                    return lambda x, t: A * torch.sin(wn * x)
+                return lambda x, t: A * torch.prod(torch.sin(wn * x), dim=1, keepdim=True)
+        return super()._create_boundary_condition(bc_type, params)
+
+    def exact_solution(self, x, t):  # heat_equation.py:112-196 (1-D / product forms)
+        es = getattr(self.config, "exact_solution", None) or {}
+        src = es if es else (getattr(self.config, "initial_condition", None) or {})
+        A, k = src.get("amplitude", 1.0), src.get("frequency", 2.0)
+        dr = self._calculate_decay_rate(k)
+        if es.get("type") == "sine_2d" and self.dimension == 2:
+            kx, ky = es.get("frequency_x", 2.0), es.get("frequency_y", 2.0)
+            tf = torch.exp(-self.alpha * ((kx * torch.pi) ** 2 + (ky * torch.pi) ** 2) * t)
+            return A * tf * torch.sin(kx * torch.pi * x[:, 0:1]) * torch.sin(ky * torch.pi * x[:, 1:2])
+        sol = torch.ones_like(x[:, 0:1])
+        for d in range(self.dimension):
+            Ld = self.config.domain[d][1] - self.config.domain[d][0]
+            sol = sol * torch.sin(2 * torch.pi * k / Ld * x[:, d : d + 1])
+        return A * torch.exp(-dr * t) * sol
+
+
+class AllenCahnEquation(PDEBase):
+    """u_t - eps^2 u_xx - u + u^3  (allen_cahn.py:39-111; caller tensors get requires_grad_ in place)."""
+
+    KIND = "allen_cahn"
+
+    def __init__(self, config: PDEConfig, **kwargs):
+        super().__init__(config)
+
+    @property
+    def epsilon(self):
+        return self.get_parameter("epsilon", default=0.1)
+
+    def _coefficients(self):
+        return (self.epsilon,)
+
+    def _prepare_model(self, model):  # allen_cahn.py does not touch the model's mode or parameter flags
+        pass
+
+    def compute_residual(self, model, x, t):
+        if x.is_leaf:
+            x.requires_grad_(True)  # allen_cahn.py:51-52 side effect on the caller's tensors
+        if t.is_leaf:
+            t.requires_grad_(True)
+        return super().compute_residual(model, x, t)
+
+    def _residual_from_jets(self, j, x, nt, nx):
+        u = j[0]
+        if self.dimension > 1:
+            return j[1] - u + u**3
+        return j[1] - self.epsilon**2 * j[nt + 2] - u + u**3
+
+    def _create_boundary_condition(self, bc_type, params):  # allen_cahn.py:131-151
+        if bc_type == "initial":
+            kind = params.get("type", "tanh")
+            if kind == "tanh":
+                if self.dimension == 1:
+                    return lambda x, t: torch.tanh(x / (2 * self.epsilon))
+                return lambda x, t: torch.tanh(torch.sum(x, dim=1, keepdim=True) / (2 * self.epsilon))
+            raise ValueError(f"Unsupported initial condition type: {kind}")
+        return super()._create_boundary_condition(bc_type, params)
+
+    def exact_solution(self, x, t):  # allen_cahn.py:113-129
+        sol = torch.ones_like(x[:, 0:1])
+        for d in range(self.dimension):
+            sol = sol * torch.tanh(x[:, d : d + 1] / (2 * self.epsilon))
+        return sol
+
+
+class KdVEquation(PDEBase):
+    """u_t + 6 u u_x + u_xxx  (kdv_equation.py:38-92; the YAML's alpha/beta are unused upstream)."""
+
+    KIND = "kdv"
+
+    def __init__(self, config: PDEConfig, **kwargs):
+        super().__init__(config)
+
+    @property
+    def speed(self):
+        return self.get_parameter("speed", default=1.0)
+
+    def _residual_from_jets(self, j, x, nt, nx):
+        if self.dimension > 1:
+            return j[1]
+        return j[1] + 6 * j[0] * j[nt + 1] + j[nt + 3]
+
+    def _create_boundary_condition(self, bc_type, params):  # kdv_equation.py:114-141
+        if bc_type == "initial":
+            kind = params.get("type", "soliton")
+            if kind == "soliton":
+                c = torch.tensor(params.get("speed", _as_float(self.speed)), dtype=torch.float32, device=self.device)
+                if self.dimension == 1:
+                    return lambda x, t: 2 * c * (1 / torch.cosh(torch.sqrt(c) * x)) ** 2
+                return lambda x, t: 2 * c * (1 / torch.cosh(torch.sqrt(c) * torch.sum(x, dim=1, keepdim=True))) ** 2
+            raise ValueError(f"Unsupported initial condition type: {kind}")
+        return super()._create_boundary_condition(bc_type, params)
+
+    def exact_solution(self, x, t):  # kdv_equation.py:94-112
+        if not self.config.exact_solution:
+            return None
+        c = torch.tensor(_as_float(self.speed), dtype=x.dtype, device=x.device)
+        xs = x if self.dimension == 1 else torch.sum(x, dim=1, keepdim=True)
+        return 2 * c * (1 / torch.cosh(torch.sqrt(c) * (xs - c * t))) ** 2
+
+
+class CahnHilliardEquation(PDEBase):
+    """1-D: u_t - d_xx(-eps^2 u_xx + c^3 - c), c = clamp(u, +-10); >= 2-D: u_t  (cahn_hilliard.py:39-160)."""
+
+    KIND = "cahn_hilliard"
+
+    def __init__(self, config: PDEConfig, **kwargs):
+        super().__init__(config)
+
+    @property
+    def epsilon(self):
+        return self.get_parameter("epsilon", default=0.1)
+
+    def _coefficients(self):
+        return (self.epsilon,)
+
+    def _prepare_model(self, model):
+        pass
+
+    def _residual_from_jets(self, j, x, nt, nx):
+        if self.dimension > 1:
+            return j[1]
+        u = j[0]
+        m = ((u >= -10.0) & (u <= 10.0)).to(u.dtype)
+        c = torch.clamp(u, -10.0, 10.0)
+        ux, uxx = j[nt + 1], j[nt + 2]
+        return j[1] + self.epsilon**2 * j[nt + 4] - m * (6 * c * ux**2 + (3 * c**2 - 1) * uxx)
+
+    def _create_boundary_condition(self, bc_type, params):  # cahn_hilliard.py:180-203
+        if bc_type == "initial":
+            kind = params.get("type", "tanh")
+            if kind == "tanh":
+                if self.dimension == 1:
+                    return lambda x, t: torch.tanh(x / (2 * self.epsilon))
+                return lambda x, t: torch.tanh(torch.sum(x, dim=1, keepdim=True) / (2 * self.epsilon))
+            if kind == "random":
+                amp = params.get("amplitude", 0.1)
+                return lambda x, t: amp * (2 * torch.rand_like(x[:, 0:1]) - 1)
+            raise ValueError(f"Unsupported initial condition type: {kind}")
+        return super()._create_boundary_condition(bc_type, params)
+
+    def exact_solution(self, x, t):  # cahn_hilliard.py:162-178
+        sol = torch.ones_like(x[:, 0:1])
+        for d in range(self.dimension):
+            sol = sol * torch.tanh(x[:, d : d + 1] / (2 * self.epsilon))
+        return sol
+
+
+class WaveEquation(PDEBase):
+    """u_tt - c^2 u_xx  (wave_equation.py:38-119)."""
+
+    KIND = "wave"
+
+    def __init__(self, config: PDEConfig, **kwargs):
+        super().__init__(config)
+
+    @property
+    def c(self):
+        return self.get_parameter("c", default=1.0)
+
+    def _coefficients(self):
+        return (self.c,)
+
+    def _prepare_model(self, model):
+        pass
+
+    def compute_residual(self, model, x, t):
+        if x.is_leaf:
+            x.requires_grad_(True)  # wave_equation.py:50-51
+        if t.is_leaf:
+            t.requires_grad_(True)
+        return super().compute_residual(model, x, t)
+
+    def _residual_from_jets(self, j, x, nt, nx):
+        if self.dimension > 1:
+            return j[2]
+        return j[2] - self.c**2 * j[nt + 2]
+
+    def _create_boundary_condition(self, bc_type, params):  # wave_equation.py:138-168
+        if bc_type == "initial":
+            kind = params.get("type", "sine")
+            if kind == "sine":
+                A, k = params.get("amplitude", 1.0), params.get("frequency", 2.0)
+                if self.dimension == 1:
+                    return lambda x, t: A * torch.sin(k * torch.pi * x)
+                return lambda x, t: A * torch.sin(k * torch.pi * torch.sum(x, dim=1, keepdim=True))
+            if kind == "sine_2d" and self.dimension == 2:
+                A, kx, ky = params.get("amplitude", 1.0), params.get("frequency_x", 2.0), params.get("frequency_y", 2.0)
+                return lambda x, t: A * torch.sin(kx * torch.pi * x[:, 0:1]) * torch.sin(ky * torch.pi * x[:, 1:2])
+            raise ValueError(f"Unsupported initial condition type: {kind}")
+        return super()._create_boundary_condition(bc_type, params)
+
+    def exact_solution(self, x, t):  # wave_equation.py:121-136
+        sol = torch.ones_like(x[:, 0:1])
+        for d in range(self.dimension):
+            sol = sol * torch.sin(2 * torch.pi * (x[:, d : d + 1] - self.c * t))
+        return sol
+
+
+class ConvectionEquation(PDEBase):
+    """u_t + v u_x  (convection_equation.py:43-78)."""
+
+    KIND = "convection"
+
+    def __init__(self, config: PDEConfig, **kwargs):
+        super().__init__(config)
+
+    @property
+    def velocity(self):
+        v = self.get_parameter("velocity", default=1.0)
+        return [v] * self.dimension if isinstance(v, (int, float)) else v
+
+    def _coefficients(self):
+        return (self.velocity[0],)
+
+    def _prepare_model(self, model):
+        pass
+
+    def _residual_from_jets(self, j, x, nt, nx):
+        if self.dimension > 1:
+            return j[1]
+        return j[1] + self.velocity[0] * j[nt + 1]
+
+    def _create_boundary_condition(self, bc_type, params):  # convection_equation.py:97-122
+        if bc_type == "initial":
+            kind = params.get("type", "sine")
+            if kind in ("sine", "sin"):
+                A, k = params.get("amplitude", 1.0), params.get("frequency", 2.0)
+                if self.dimension == 1:
+                    return lambda x, t: A * torch.sin(k * torch.pi * x)
+                return lambda x, t: A * torch.sin(k * torch.pi * torch.sum(x, dim=1, keepdim=True))
+            raise ValueError(f"Unsupported initial condition type: {kind}")
+        return super()._create_boundary_condition(bc_type, params)
+
+    def exact_solution(self, x, t):  # convection_equation.py:80-95
+        sol = torch.ones_like(x[:, 0:1])
+        for d in range(self.dimension):
+            sol = sol * torch.sin(2 * torch.pi * (x[:, d : d + 1] - self.velocity[d] * t))
+        return sol
+
+
+class BlackScholesEquation(PDEBase):
+    """V_t + 1/2 sigma^2 S^2 V_SS + r S V_S - r V  (black_scholes.py:44-93)."""
+
+    KIND = "black_scholes"
+
+    def __init__(self, config: PDEConfig, **kwargs):
+        super().__init__(config)
+
+    @property
+    def sigma(self):
+        return self.get_parameter("sigma", default=0.2)
+
+    @property
+    def r(self):
+        return self.get_parameter("r", default=0.05)
+
+    def _coefficients(self):
+        return (self.sigma, self.r)
+
+    def _residual_from_jets(self, j, x, nt, nx):
+        if self.dimension > 1:
+            return j[1]
+        S = x[:, 0]
+        return j[1] + 0.5 * self.sigma**2 * S**2 * j[nt + 2] + self.r * S * j[nt + 1] - self.r * j[0]
+
+    def _create_boundary_condition(self, bc_type, params):  # black_scholes.py:128-150
+        if bc_type == "initial":
+            kind = params.get("type", "call_option")
+            if kind in ("call_option", "option"):
+                K = params.get("strike_price", params.get("strike", 1.0))
+                if self.dimension == 1:
+                    return lambda x, t: torch.maximum(x - K, torch.zeros_like(x))
+                return lambda x, t: torch.maximum(torch.sum(x, dim=1, keepdim=True) - K, torch.zeros_like(x[:, 0:1]))
+            raise ValueError(f"Unsupported initial condition type: {kind}")
+        return super()._create_boundary_condition(bc_type, params)
+
+    def exact_solution(self, x, t):  # black_scholes.py:95-126 (as written upstream, erf in place of the normal CDF)
+        if not self.config.exact_solution:
+            return None
+        K = self.config.exact_solution.get("strike_price", 1.0)
+        sol = torch.ones_like(x[:, 0:1])
+        for d in range(self.dimension):
+            xd = x[:, d : d + 1]
+            d1 = (torch.log(xd / K) + (self.r + 0.5 * self.sigma**2) * t) / (self.sigma * torch.sqrt(t))
+            d2 = d1 - self.sigma * torch.sqrt(t)
+            sol = sol * (xd * torch.erf(d1) - K * torch.exp(-self.r * t) * torch.erf(d2))
+        return sol
+
+
+class PendulumEquation(PDEBase):
+    """u_tt + (g/L) sin u  (pendulum_equation.py:51-94)."""
+
+    KIND = "pendulum"
+
+    def __init__(self, config: PDEConfig, **kwargs):
+        super().__init__(config)
+
+    @property
+    def g(self):
+        return self.get_parameter("g", default=9.81)
+
+    @property
+    def L(self):
+        return self.get_parameter("L", default=1.0)
+
+    def _coefficients(self):
+        g, L = self.g, self.L
+        return (g / L,)
+
+    def _residual_from_jets(self, j, x, nt, nx):
+        return j[2] + (self.g / self.L) * torch.sin(j[0])
+
+    def _create_boundary_condition(self, bc_type, params):  # pendulum_equation.py:125-155
+        if bc_type == "initial":
+            kind = params.get("type", "small_angle")
+            if kind == "small_angle":
+                th = params.get("initial_angle", 0.1)
+                return lambda x, t: torch.full_like(x, th)
+            if kind == "sine":
+                A, f = params.get("amplitude", 1.0), params.get("frequency", 1.0)
+                return lambda x, t: A * torch.sin(f * x)
+            if kind == "gaussian":
+                A, c0, sg = params.get("amplitude", 1.0), params.get("center", 0.0), params.get("sigma", 0.1)
+                return lambda x, t: A * torch.exp(-((x - c0) ** 2) / (2 * sg**2))
+            raise ValueError(f"Unknown initial condition type: {kind}")
+        return super()._create_boundary_condition(bc_type, params)
+
+    def exact_solution(self, x, t):  # pendulum_equation.py:96-123
+        if not self.config.exact_solution:
+            return None
+        kind = self.config.exact_solution.get("type", "small_angle")
+        if kind == "small_angle":
+            th = self.config.exact_solution.get("initial_angle", 0.1)
+            omega = (_as_float(self.g) / _as_float(self.L)) ** 0.5
+            return th * torch.cos(omega * t)
+        if kind == "sine":
+            A, f = self.config.exact_solution.get("amplitude", 1.0), self.config.exact_solution.get("frequency", 1.0)
+            return A * torch.sin(f * (x + t))
+        raise ValueError(f"Unknown exact solution type: {kind}")
