@@ -8,7 +8,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpinnjet.so")
+LIB_PATH = os.environ.get("PINN_LIB") or os.path.join(_HERE, "libpinnjet.so")  # PINN_LIB: developer builds
 CSRC = os.path.join(_HERE, "csrc")
 
 PINN_ABI_VERSION = 1

@@ -17,12 +17,58 @@ namespace pinn {
 constexpr int kMaxOrd = 4;
 
 // ---------------------------------------------------------------------------
+// sin and cos together, ~1 ulp for |x| < 2^13: Cody-Waite reduction by pi/2 in three exact pieces, then the
+// Cephes single-precision minimax polynomials on [-pi/4, pi/4].  The Fourier features evaluate 2*M of these per
+// point and SIREN one per hidden unit; the library sincosf (Payne-Hanek capable, ~150 instructions) made the
+// encoding the slowest phase of a tile.  Larger arguments take the library path.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void fast_sincosf(float x, float* sn, float* cs) {
+  if (fabsf(x) > 8192.0f) {
+    sincosf(x, sn, cs);
+    return;
+  }
+  const float k = rintf(x * 0.63661977236758134308f);  // x * 2/pi
+  float r = fmaf(k, -1.5703125f, x);
+  r = fmaf(k, -4.837512969970703125e-4f, r);
+  r = fmaf(k, -7.54978995489188216e-8f, r);
+  const float z = r * r;
+  float s = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  s = fmaf(s * z, r, r);
+  float c = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  c = fmaf(c * z, z, fmaf(-0.5f, z, 1.0f));
+  const int q = static_cast<int>(k) & 3;
+  const float s1 = (q & 1) ? c : s;
+  const float c1 = (q & 1) ? s : c;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+// ---------------------------------------------------------------------------
+// tanh, branch-free, ~1-2 ulp: |z| < 0.625 -> the odd minimax polynomial the ROCm device library uses;
+// otherwise 1 - 2 / (exp(2|z|) + 1) on v_exp_f32 / v_rcp_f32 (the argument error of the hardware exp2 is damped
+// by 2e/(e+1)^2 <= 0.35 in this range).  The library tanhf diverges on the 0.625 threshold, so a wave pays
+// for both of its branches (~45 instructions); this is ~20.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fast_tanhf(float z) {
+  const float a = fabsf(z);
+  const float t = z * z;
+  float p = fmaf(-0.005700020585209131f, t, 0.02063407190144062f);
+  p = fmaf(p, t, -0.053737930953502655f);
+  p = fmaf(p, t, 0.13331416249275208f);
+  p = fmaf(p, t, -0.3333328068256378f);
+  const float small = fmaf(z * t, p, z);
+  const float e = __builtin_amdgcn_exp2f(a * 2.8853900817779268f);  // exp(2a); +inf for large a -> big = 1
+  const float big = copysignf(fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f), z);
+  return a < 0.625f ? small : big;
+}
+
+// ---------------------------------------------------------------------------
 // f[k] = k-th derivative of the activation at z, k = 0..ORD (ORD <= 5)
 // ---------------------------------------------------------------------------
 template <int ACT, int ORD>
 __device__ __forceinline__ void act_derivs(float z, float w, float (&f)[6]) {
   if constexpr (ACT == PINN_ACT_TANH) {
-    const float y = tanhf(z);
+    const float y = fast_tanhf(z);
     const float y2 = y * y;
     const float f1 = 1.0f - y2;
     f[0] = y;
@@ -33,7 +79,7 @@ __device__ __forceinline__ void act_derivs(float z, float w, float (&f)[6]) {
     if constexpr (ORD >= 5) f[5] = 8.0f * f1 * (2.0f - 15.0f * y2 + 15.0f * y2 * y2);
   } else if constexpr (ACT == PINN_ACT_SIN) {
     float s, c;
-    sincosf(w * z, &s, &c);
+    fast_sincosf(w * z, &s, &c);
     const float w2 = w * w;
     f[0] = s;
     f[1] = w * c;
@@ -130,6 +176,60 @@ template <int ACT, int NT, int NX>
 __device__ __forceinline__ void act_bwd(float w, const float* z, const float* ab, float* zb) {
   float f[6];
   act_derivs<ACT, MaxOf<NT, NX>::v + 1>(z[0], w, f);
+  float z0b = f[1] * ab[0];
+  z0b += dir_bwd<NT>(f, z + 1, ab + 1, zb + 1);
+  z0b += dir_bwd<NX>(f, z + 1 + NT, ab + 1 + NT, zb + 1 + NT);
+  zb[0] = z0b;
+}
+
+// ---------------------------------------------------------------------------
+// Tape form.  The reverse sweep needs f'(z), f''(z), ... at every hidden pre-activation.  For tanh
+// and sigmoid these are polynomials of the activation VALUE, so the tape keeps y = f(z) in slot 0 and
+// the reverse sweep evaluates no transcendental; for the others slot 0 keeps z.
+// ---------------------------------------------------------------------------
+template <int ACT>
+struct ActTape {
+  static constexpr bool value_is_output = (ACT == PINN_ACT_TANH || ACT == PINN_ACT_SIGMOID);
+};
+
+template <int ACT, int ORD>
+__device__ __forceinline__ void act_derivs_tape(float t0, float w, float (&f)[6]) {
+  if constexpr (ACT == PINN_ACT_TANH) {
+    const float y = t0, y2 = y * y, f1 = 1.0f - y2;
+    f[0] = y;
+    f[1] = f1;
+    if constexpr (ORD >= 2) f[2] = -2.0f * y * f1;
+    if constexpr (ORD >= 3) f[3] = f1 * (6.0f * y2 - 2.0f);
+    if constexpr (ORD >= 4) f[4] = 8.0f * y * f1 * (2.0f - 3.0f * y2);
+    if constexpr (ORD >= 5) f[5] = 8.0f * f1 * (2.0f - 15.0f * y2 + 15.0f * y2 * y2);
+  } else if constexpr (ACT == PINN_ACT_SIGMOID) {
+    const float s = t0, f1 = s * (1.0f - s);
+    f[0] = s;
+    f[1] = f1;
+    if constexpr (ORD >= 2) f[2] = f1 * (1.0f - 2.0f * s);
+    if constexpr (ORD >= 3) f[3] = f1 * (1.0f - 6.0f * f1);
+    if constexpr (ORD >= 4) f[4] = f[2] * (1.0f - 12.0f * f1);
+    if constexpr (ORD >= 5) f[5] = f[3] * (1.0f - 12.0f * f1) - 12.0f * f[2] * f[2];
+  } else {
+    act_derivs<ACT, ORD>(t0, w, f);
+  }
+}
+
+// activation jets replayed from a tape record [t0, z_1 .. z_{K-1}]
+template <int ACT, int NT, int NX>
+__device__ __forceinline__ void act_fwd_tape(float w, const float* z, float* a) {
+  float f[6];
+  act_derivs_tape<ACT, MaxOf<MaxOf<NT, NX>::v, 1>::v>(z[0], w, f);
+  a[0] = f[0];
+  dir_fwd<NT>(f, z + 1, a + 1);
+  dir_fwd<NX>(f, z + 1 + NT, a + 1 + NT);
+}
+
+// adjoint of the activation jets from a tape record
+template <int ACT, int NT, int NX>
+__device__ __forceinline__ void act_bwd_tape(float w, const float* z, const float* ab, float* zb) {
+  float f[6];
+  act_derivs_tape<ACT, MaxOf<NT, NX>::v + 1>(z[0], w, f);
   float z0b = f[1] * ab[0];
   z0b += dir_bwd<NT>(f, z + 1, ab + 1, zb + 1);
   z0b += dir_bwd<NX>(f, z + 1 + NT, ab + 1 + NT, zb + 1 + NT);

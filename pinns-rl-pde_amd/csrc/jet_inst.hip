@@ -1,6 +1,6 @@
 // One translation unit per (time_order, space_order) stream set; the Makefile compiles this file
 // several times with -DPINN_NT=.. -DPINN_NX=.. so the instantiations build in parallel.
-#include "jet_kernel.h"
+#include "jet_kernel_wide.h"
 
 #ifndef PINN_NT
 #error "compile with -DPINN_NT=<0..2> -DPINN_NX=<0..4>"
@@ -10,7 +10,12 @@
 #define PINN_CAT(a, b, c) PINN_CAT2(a, b, c)
 
 namespace pinn {
-hipError_t PINN_CAT(launch_jet_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
-  return launch_jet<PINN_NT, PINN_NX>(a, bwd, grid, stream);
+// stream-serial kernel: any K, widths up to 256
+hipError_t PINN_CAT(launch_jet_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, int occ, hipStream_t stream) {
+  return launch_jet<PINN_NT, PINN_NX>(a, bwd, grid, occ, stream);
+}
+// wide kernel: all K streams LDS-resident, persistent dW accumulators (K * Hmax small enough)
+hipError_t PINN_CAT(launch_jetw_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
+  return launch_jet_wide<PINN_NT, PINN_NX>(a, bwd, grid, stream);
 }
 }  // namespace pinn

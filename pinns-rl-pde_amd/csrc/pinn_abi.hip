@@ -4,12 +4,18 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
-#include "jet_kernel.h"
+#include "jet_kernel_wide.h"
 
 namespace pinn {
-#define PINN_DECL(nt, nx) hipError_t launch_jet_##nt##_##nx(const KernelArgs&, bool, int, hipStream_t);
+#define PINN_DECL(nt, nx)                                                               \
+  hipError_t launch_jet_##nt##_##nx(const KernelArgs&, bool, int, int, hipStream_t); \
+  hipError_t launch_jetw_##nt##_##nx(const KernelArgs&, bool, int, hipStream_t);
+#ifdef PINN_DEV /* developer build: stream set (1, 2) only */
+PINN_DECL(1, 2)
+#else
 PINN_DECL(0, 0)
 PINN_DECL(1, 0)
 PINN_DECL(1, 1)
@@ -18,7 +24,10 @@ PINN_DECL(1, 3)
 PINN_DECL(1, 4)
 PINN_DECL(2, 0)
 PINN_DECL(2, 2)
+#endif
 #undef PINN_DECL
+
+static unsigned long long* g_stamps = nullptr;  // diagnostic builds: device buffer for in-kernel phase timing
 
 static thread_local char g_err[512] = "";
 
@@ -140,19 +149,50 @@ static bool pick_streams(int nt, int nx, int* knt, int* knx) {
   return false;
 }
 
-static hipError_t dispatch(int nt, int nx, const KernelArgs& a, bool bwd, int grid, hipStream_t st) {
-#define PINN_CASE(NT_, NX_) if (nt == NT_ && nx == NX_) return launch_jet_##NT_##_##NX_(a, bwd, grid, st);
+static hipError_t dispatch(int nt, int nx, const KernelArgs& a, bool bwd, int grid, int occ, bool wide, hipStream_t st) {
+#define PINN_CASE(NT_, NX_)                                                                   \
+  if (nt == NT_ && nx == NX_)                                                                 \
+    return wide ? launch_jetw_##NT_##_##NX_(a, bwd, grid, st) : launch_jet_##NT_##_##NX_(a, bwd, grid, occ, st);
+#ifdef PINN_DEV
+  PINN_CASE(1, 2)
+#else
   PINN_CASE(0, 0) PINN_CASE(1, 0) PINN_CASE(1, 1) PINN_CASE(1, 2) PINN_CASE(1, 3) PINN_CASE(1, 4) PINN_CASE(2, 0) PINN_CASE(2, 2)
+#endif
 #undef PINN_CASE
   return hipErrorInvalidValue;
 }
 
-static int grid_for(const NetDev& n, int K, long long N, bool bwd, size_t* lds_out) {
-  const size_t lds = jet_lds_bytes(K, n.hmax, bwd);
+// Workgroups per CU a launch is sized (and register-budgeted) for.  PINN_OCC=1|2 overrides for experiments.
+static int occupancy_for(const NetDev& n, size_t lds, bool bwd) {
+  int occ = (n.hmax <= 128 && (int)(kLdsLimit / lds) >= 2) ? 2 : 1;
+  if (const char* e = getenv("PINN_OCC")) {
+    const int v = atoi(e);
+    if (v == 1) occ = 1;
+  }
+  (void)bwd;
+  return occ;
+}
+
+// Kernel variant: "wide" (all K streams LDS-resident, persistent dW accumulators) whenever it fits, else the
+// stream-serial kernel.  PINN_KERNEL=stream|wide overrides for experiments and tests.
+static bool use_wide(const NetDev& n, int K, bool bwd) {
+  const bool fits = jet_wide_fits(K, n.hmax, bwd);
+  if (const char* e = getenv("PINN_KERNEL")) {
+    if (!strcmp(e, "stream")) return false;
+  }
+  return fits;
+}
+
+static int grid_for(const NetDev& n, int K, long long N, bool bwd, size_t* lds_out, int* occ_out = nullptr,
+                    bool* wide_out = nullptr) {
+  const bool wide = use_wide(n, K, bwd);
+  if (wide_out) *wide_out = wide;
+  const size_t lds = wide ? jet_wide_lds_bytes(K, n.hmax, bwd) : jet_lds_bytes(K, n.hmax, bwd);
   if (lds_out) *lds_out = lds;
   if (lds > kLdsLimit) return 0;
   const long long ntiles = (N + kT - 1) / kT;
-  const int per_cu = (int)(kLdsLimit / lds) >= 2 ? 2 : 1;
+  const int per_cu = wide ? 1 : occupancy_for(n, lds, bwd);
+  if (occ_out) *occ_out = per_cu;
   long long g = (long long)num_cus() * per_cu;
   if (g > ntiles) g = ntiles;
   return (int)(g < 1 ? 1 : g);
@@ -175,7 +215,9 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
   if (rc) return rc;
   const int K = 1 + knt + knx;
   size_t lds = 0;
-  const int grid = grid_for(a.net, K, N, bwd, &lds);
+  int occ = 1;
+  bool wide = false;
+  const int grid = grid_for(a.net, K, N, bwd, &lds, &occ, &wide);
   if (grid == 0)
     return fail(PINN_ERR_UNSUPPORTED, "LDS need %zu B > %zu B (K=%d streams, width %d%s)", lds, kLdsLimit, K, a.net.hmax, bwd ? ", reverse sweep" : "");
   if (pde) {
@@ -200,6 +242,7 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
   a.residual_out = residual_out;
   a.loss_sum = loss_sum;
   a.res_bar = res_bar;
+  a.stamps = g_stamps;
   if (bwd) {
     const int ntile = a.net.hmax > 128 ? 2 : 1;
     a.tape_stride = jet_tape_floats_per_wg(K, a.net.n_layers, ntile);
@@ -209,7 +252,7 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
     if ((reinterpret_cast<uintptr_t>(workspace) & 15)) return fail(PINN_ERR_MISALIGNED, "workspace is not 16-byte aligned");
     a.tape = static_cast<float*>(workspace);
   }
-  const hipError_t e = dispatch(knt, knx, a, bwd, grid, static_cast<hipStream_t>(stream));
+  const hipError_t e = dispatch(knt, knx, a, bwd, grid, occ, wide, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)e, hipGetErrorString(e));
   return PINN_OK;
 }
@@ -305,5 +348,8 @@ int pinn_residual_backward(const PinnNetDesc* net, const float* const* weights, 
   return run(net, weights, weight_grads, pde, x, t, N, nt, nx, MODE_PDE, 0.0f, nullptr, nullptr, nullptr, nullptr,
              workspace, ws_bytes, true, stream, residual_cotangent);
 }
+
+/* Diagnostic hook (not part of the documented ABI): device buffer of grid*4*16 uint64 for -DPINN_STAMPS builds. */
+void pinn_debug_set_stamps(void* device_buffer) { g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
 }  // extern "C"

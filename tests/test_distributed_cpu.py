@@ -1,0 +1,108 @@
+"""world_size-2 gloo test of the data-parallel path (one all-reduce of [gradients || loss]) on CPU.
+
+The HIP engine cannot run here, so the test plugs an ORACLE-backed stand-in under the same host code
+(`distributed.sharded_compute_loss` -> `PDEBase.compute_loss(..., n_total, aux_scale)`); what is verified is the
+sharding arithmetic: summed shard gradients == full-batch gradient, replicas stay identical."""
+
+import math
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_case, rel_l2
+
+import oracle as O
+import pinnrl_amd  # noqa: F401
+from pinnrl_amd import distributed as D
+from pinnrl_amd import pdes as P
+
+
+class OracleModel(torch.nn.Module):
+    def __init__(self, spec, sd):
+        super().__init__()
+        self.spec = spec
+        self.names = list(sd)
+        self.params = torch.nn.ParameterList([torch.nn.Parameter(v.clone(), requires_grad=not k.endswith("fourier.B")) for k, v in sd.items()])
+
+    def forward(self, inp):
+        return O.network_forward(self.spec, dict(zip(self.names, self.params)), inp)
+
+
+class OracleBurgers(P.BurgersEquation):
+    """Same host logic; the residual term comes from the CPU oracle instead of the HIP kernel."""
+
+    def _residual_loss(self, model, x, t, n_total=None):
+        spec = O.PdeSpec(name="burgers", parameters={"nu": float(self.nu)})
+        r = O.compute_residual(spec, model, x, t)
+        n = n_total if n_total is not None else x.shape[0]
+        return (r**2).sum() / n
+
+
+def _pde():
+    return OracleBurgers(P.PDEConfig(name="b", domain=[(-1.0, 1.0)], time_domain=(0.0, 1.0), parameters={"nu": 0.01 / math.pi},
+                                     boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}},
+                                     initial_condition={"type": "sine", "amplitude": -1.0, "frequency": 1.0},
+                                     exact_solution={}, device=torch.device("cpu")))
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    spec, pde_s, sd, a, m = load_case("burgers_fourier_3x32")
+    torch.manual_seed(100 + rank)  # replicas start DIFFERENT; the broadcast must fix that
+    model = OracleModel(spec, {k: v + 0.01 * torch.randn_like(v) for k, v in sd.items()})
+    D.broadcast_parameters(model, src=0)
+    x, t = torch.from_numpy(a["x"])[:101], torch.from_numpy(a["t"])[:101]  # odd count: uneven shards
+    pde = _pde()
+    losses = D.sharded_compute_loss(pde, model, x, t)
+    losses["total"].backward()
+    red = D.all_reduce_gradients(list(model.parameters()), scalars=[losses["residual"]])
+    flat = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+    theta = torch.cat([p.detach().flatten() for p in model.parameters()])
+    out.put((rank, flat, float(red[0]), theta))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_equals_full_batch():
+    world, port = 2, 29533 + os.getpid() % 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda z: z[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, g0, L0, th0), (_, g1, L1, th1) = res
+    assert torch.equal(th0, th1), "broadcast_parameters must make replicas identical"
+    assert torch.equal(g0, g1) and L0 == L1, "every rank must hold the same reduced gradient and loss"
+    # single-process full batch from rank 0's parameters
+    spec, pde_s, sd, a, m = load_case("burgers_fourier_3x32")
+    model = OracleModel(spec, sd)
+    with torch.no_grad():
+        off = 0
+        for p in model.parameters():
+            p.copy_(th0[off : off + p.numel()].view_as(p))
+            off += p.numel()
+    x, t = torch.from_numpy(a["x"])[:101], torch.from_numpy(a["t"])[:101]
+    losses = _pde().compute_loss(model, x, t)
+    losses["total"].backward()
+    want = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+    assert rel_l2(g0, want) < 1e-5
+    assert abs(L0 - float(losses["residual"])) <= 1e-6 * abs(float(losses["residual"]))
+
+
+def test_shard_bounds_partition():
+    for n in (0, 1, 7, 100, 49729):
+        for w in (1, 2, 3, 8):
+            b = [D.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1

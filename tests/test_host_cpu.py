@@ -1,0 +1,171 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports what include/pinn_jet.h declares, and the host
+mirror of the reference's interface (config, network containers, PDE host logic, samplers) behaves like upstream."""
+
+import ctypes
+import math
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import CASES, ROOT, load_case
+
+import pinnrl_amd  # noqa: F401
+from pinnrl_amd import _lib
+from pinnrl_amd.config import Config, ModelConfig, TrainingConfig
+from pinnrl_amd.neural_networks import PINNModel
+from pinnrl_amd import pdes as P
+
+CPU = torch.device("cpu")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "pinn_jet.h")).read()
+    declared = set(re.findall(r"\b(pinn_[a-z_]+)\s*\(", hdr))
+    assert declared >= set(_lib.EXPORTS)
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libpinnjet.so does not export {name}"
+    assert lib.pinn_abi_version() == _lib.PINN_ABI_VERSION
+
+
+def test_descriptor_queries_without_a_gpu():
+    lib = _lib.load()
+    from pinnrl_amd import engine as E
+
+    for kind, want in {"burgers": (1, 2), "heat": (1, 1), "kdv": (1, 3), "cahn_hilliard": (1, 4), "wave": (2, 2),
+                       "pendulum": (2, 0), "convection": (1, 1)}.items():
+        assert E.pde_streams(E.pde_desc(kind)) == want
+    assert E.pde_streams(E.pde_desc("cahn_hilliard", dimension=2)) == (1, 0)  # reference drops 2-D spatial terms
+    spec, pde, sd, a, m = load_case("burgers_fourier_4x128")
+    prog = E.NetProgram("fourier", "tanh", 2, [128, 128, 128, 1], list(sd.values()), [False] + [True] * 8, mapping_size=32)
+    assert prog.flops_per_point() == 82304
+    nbytes = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), 49729, 1, 2)
+    assert nbytes > 0 and nbytes % 16 == 0
+    bad = E.NetProgram("fourier", "tanh", 2, [100, 1], [sd["model.fourier.B"]] + [torch.zeros(1)] * 4, [False] + [True] * 4,
+                       mapping_size=32)
+    assert lib.pinn_workspace_bytes(ctypes.byref(bad.desc), 100, 1, 2) == 0  # width 100: not a multiple of 32
+
+
+def test_model_config_matches_reference_semantics():
+    mc = ModelConfig(input_dim=2, hidden_dim=64, output_dim=1, num_layers=3, activation="tanh", architecture="resnet")
+    assert mc.hidden_dims == [64, 64, 64] and mc.num_blocks == 3
+    assert mc.get("omega_0", 30.0) is None  # class attribute None shadows the default, as upstream
+    assert mc.get("mapping_size", 7) == 32 and mc["scale"] == 10.0
+    with pytest.raises(ValueError):
+        TrainingConfig(optimizer="sgd")
+    tc = TrainingConfig()
+    assert tc.loss_weights["data"] == 1.0 and tc["optimizer_config"]["learning_rate"] == tc.learning_rate
+
+
+def _cfg(spec):
+    cfg = Config.__new__(Config)
+    cfg.device = CPU
+    cfg.model = ModelConfig(input_dim=spec.input_dim, hidden_dim=spec.hidden_dim, output_dim=1, num_layers=spec.num_layers,
+                            activation=spec.activation, architecture=spec.architecture)
+    cfg.model.mapping_size, cfg.model.scale = spec.mapping_size, spec.scale
+    cfg.model.omega_0, cfg.model.num_heads = spec.omega_0, spec.num_heads
+    if spec.architecture == "resnet":
+        cfg.model.num_blocks = spec.num_blocks
+    return cfg
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_pinnmodel_theta0_and_state_dict_match_reference(tag):
+    spec, pde, sd, a, m = load_case(tag)
+    torch.manual_seed(m["seed"])
+    model = PINNModel(_cfg(spec), device=CPU)
+    got = model.state_dict()
+    assert list(got) == list(sd)
+    for k in sd:
+        assert torch.equal(got[k], sd[k]), k
+    assert model.architecture_name == spec.architecture
+    assert model.count_parameters() == sum(v.numel() for k, v in sd.items() if not k.endswith("fourier.B"))
+
+
+def test_unsupported_inputs_fail_loudly_not_silently():
+    spec, pde, sd, a, m = load_case("burgers_fourier_3x32")
+    model = PINNModel(_cfg(spec), device=CPU)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.zeros(4, 2))
+    cfg = _cfg(spec)
+    cfg.model.architecture = "fno"
+    with pytest.raises(NotImplementedError):
+        PINNModel(cfg, device=CPU)
+    cfg = _cfg(spec)
+    cfg.model.activation = "swish"
+    with pytest.raises(ValueError, match="Unsupported activation"):
+        PINNModel(cfg, device=CPU)
+
+
+def _burgers(**kw):
+    return P.BurgersEquation(P.PDEConfig(
+        name="b", domain=[(-1.0, 1.0)], time_domain=(0.0, 1.0), parameters={"nu": 0.01 / math.pi},
+        boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}},
+        initial_condition={"type": "sine", "amplitude": -1.0, "frequency": 1.0}, exact_solution={}, device=CPU, **kw))
+
+
+def test_pde_host_logic_and_samplers():
+    pde = _burgers()
+    assert list(pde.boundary_conditions) == ["dirichlet", "initial"]  # the IC joins the BC dict (pde_base.py:483-486)
+    assert pde.config.input_dim == 2 and pde.config.output_dim == 1
+    for n, rows in [(5000, 4900), (50000, 49729), (100, 100)]:
+        x, t = pde.generate_collocation_points(n, strategy="uniform")
+        assert x.shape == (rows, 1) and t.shape == (rows, 1)
+        assert float(x.min()) >= -1 and float(x.max()) <= 1 and float(t.min()) >= 0 and float(t.max()) <= 1
+    x, t = pde.generate_collocation_points(333, strategy="stratified")
+    assert x.shape == (333, 1)
+    x, t = pde.generate_collocation_points(400, strategy="adaptive")  # no agent -> uniform fallback (pde_base.py:1074)
+    assert x.shape == (400, 1)
+    with pytest.raises(ValueError, match="Unknown sampling strategy"):
+        pde.generate_collocation_points(10, strategy="sobol")
+    e = torch.linspace(-2, 2, 9).reshape(-1, 1)
+    assert torch.allclose(pde._apply_loss_fn(e), (e**2).mean())
+    pde.config.training = {"loss_function": "mae"}
+    assert torch.allclose(pde._apply_loss_fn(e), e.abs().mean())
+    ch2 = P.CahnHilliardEquation(P.PDEConfig(name="c", domain=[(0.0, 1.0), (0.0, 1.0)], time_domain=(0.0, 1.0), parameters={},
+                                            boundary_conditions={}, initial_condition={"type": "tanh"}, exact_solution={},
+                                            dimension=2, device=CPU))
+    x, t = ch2.generate_collocation_points(1000)
+    assert x.shape == (1000, 2) and t.shape == (1000, 1)
+
+
+def test_adaptive_sampling_with_duck_typed_agent():
+    class Agent:  # mirrors the fake used upstream (tests/unit_tests/test_pde_sampling.py:192-210)
+        def __init__(self):
+            self.eps_updates = 0
+
+        def select_action(self, pts):
+            return torch.rand(pts.shape[0], 1)
+
+        def update_epsilon(self, n):
+            self.eps_updates += 1
+
+    pde = _burgers()
+    pde.rl_agent = Agent()
+    for _ in range(3):
+        x, t = pde.generate_collocation_points(700, strategy="adaptive")
+        assert x.shape == (700, 1) and t.shape == (700, 1)  # exactly N
+    assert len(pde.collocation_history) == 3 and pde.rl_agent.eps_updates == 2
+
+
+def test_derivative_order_limits_raise_before_any_launch():
+    pde = _burgers()
+    model = PINNModel(_cfg(load_case("burgers_fourier_3x32")[0]), device=CPU)
+    x, t = torch.zeros(4, 1), torch.zeros(4, 1)
+    with pytest.raises(ValueError, match="Maximum order is 2"):
+        pde.compute_derivatives(model, x, t, temporal_derivatives=[3])
+    with pytest.raises(ValueError, match="Maximum order is 4"):
+        pde.compute_derivatives(model, x, t, spatial_derivatives=[5])
+    with pytest.raises(NotImplementedError, match="not a pinnrl_amd network"):
+        pde.compute_residual(torch.nn.Linear(2, 1), x, t)
+
+
+def test_inverse_mode_parameter_registry():
+    pde = _burgers(trainable_parameters=["nu"], parameter_initial_guesses={"nu": 0.05})
+    nu = pde.get_parameter("nu")
+    assert isinstance(nu, torch.nn.Parameter) and abs(float(nu) - 0.05) < 1e-9
+    assert pde._true_parameters["nu"] == pytest.approx(0.01 / math.pi)
+    assert pde._has_trainable_coefficients()
+    assert list(pde.get_trainable_parameter_values()) == ["nu"]
