@@ -26,6 +26,19 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
+    (profiles/r01_bench.json, made by tools/profile_summary.py): FETCH_SIZE (x2: gfx950 counts 64 B per 128-B
+    request) + WRITE_SIZE, both KiB.  None when no profile has been committed."""
+    path = os.path.join(ROOT, "profiles", "r01_bench.json")
+    try:
+        with open(path) as f:
+            h = json.load(f).get("hbm_bytes_per_launch")
+        return None if not h else float(h["read_x2"] + h["write"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def host_threads() -> int:
     """Threads for the CPU leg: this process's CPU share (a 1-GPU box grants 16 cores), never the whole host."""
     try:
@@ -150,8 +163,8 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                "kernel": "pinn::jet_kernel<1,2,1,true>", "kernel_ms": kern_ms,
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(),
+                "kernel": "pinn::jet_kernel_wide<tanh, NT=1, NX=2, reverse>", "kernel_ms": kern_ms,
                 "flops_per_point": flops_pt,
             },
             "residual_l2": math.sqrt(float(loss_sum) / n_global),

@@ -20,6 +20,7 @@ from .reference_path import (  # noqa: F401
     apply_loss_fn,
     compute_derivatives,
     compute_loss_terms,
+    compute_loss_terms_heat,
     compute_residual,
     init_state_dict,
     network_forward,

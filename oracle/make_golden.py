@@ -236,6 +236,24 @@ def run_case(tag: str, spec: O.ArchSpec, pde: O.PdeSpec, n_pts: int, seed: int, 
           f"g={manifest[tag]['fp32_vs_fp64']['grad']:.1e}")
 
 
+def check_loss_terms():
+    """`compute_loss` restatements (base class and HeatEquation's own) against the reference, value by value."""
+    for name, fn, nb in (("burgers", O.compute_loss_terms, None), ("heat", O.compute_loss_terms_heat, 61)):
+        pde = pde_spec(name)
+        spec = O.ArchSpec("fourier", hidden_dim=32, num_layers=3, mapping_size=16, scale=4.0)
+        torch.manual_seed(21)
+        model = make_ref_model(spec)
+        ref = make_ref_pde(pde)
+        x, t = points(pde, ref, 123, 22)
+        want = ref.compute_loss(model, x.clone(), t.clone())
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        got = fn(pde, lambda z: O.network_forward(spec, sd, z), x.clone(), t.clone())
+        for k in ("residual", "boundary", "initial", "total"):
+            a, b = float(got[k].detach()), float(want[k].detach())
+            assert abs(a - b) <= 1e-6 * abs(b) + 1e-12, f"compute_loss[{name}][{k}]: oracle {a} vs reference {b}"
+        print(f"compute_loss restatement == reference for {name}: " + ", ".join(f"{k}={float(want[k].detach()):.6g}" for k in ("residual", "boundary", "initial", "total")))
+
+
 def quirk_witnesses(manifest: dict):
     """The behavioural quirks of SURVEY §0.3/§0.4, pinned as data."""
     w = {}
@@ -290,6 +308,7 @@ def main():
     ]
     for tag, spec, pde, n, seed in cases:
         run_case(tag, spec, pde, n, seed, manifest)
+    check_loss_terms()
     quirk_witnesses(manifest)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True, default=float)

@@ -588,3 +588,49 @@ def compute_loss_terms(pde: PdeSpec, model_fn, x: Tensor, t: Tensor) -> Dict[str
         rw, bw, iw = 1.0, 10.0, 10.0
     total = rw * residual_loss + bw * boundary_loss + iw * initial_loss
     return {"residual": residual_loss, "boundary": boundary_loss, "initial": initial_loss, "total": total}
+
+
+def compute_loss_terms_heat(pde: PdeSpec, model_fn, x: Tensor, t: Tensor, num_boundary_points: Optional[int] = None,
+                            num_initial_points: Optional[int] = None) -> Dict[str, Tensor]:
+    """`HeatEquation.compute_loss` (pdes/heat_equation.py:375-623), 1-D, forward mode, fixed weights, no smoothness.
+
+    Periodic BC enforced on u AND on du/dx at the two ends (boundary du/dx by autograd w.r.t. the boundary points,
+    heat_equation.py:420-445), time points clustered in the first 1 % of the horizon, IC points clustered near the ends.
+    """
+    residual = compute_residual(pde, model_fn, x, t)
+    lf = lambda e: apply_loss_fn(e, pde.loss_function, pde.huber_delta)  # noqa: E731
+    residual_loss = lf(residual)
+    nbp = num_boundary_points if num_boundary_points is not None else max(len(x) // 10, 10)
+    t_max = pde.time_domain[1]
+    t_early = t_max * 0.01
+    n_early = max(nbp // 4, 1)
+    tb = torch.cat([torch.linspace(0, t_early, n_early), torch.linspace(t_early, t_max, nbp - n_early)]).reshape(-1, 1)
+    x_lo, x_hi = pde.domain[0]
+    pl = torch.cat([torch.full((nbp, 1), x_lo), tb], dim=1).requires_grad_(True)
+    pr = torch.cat([torch.full((nbp, 1), x_hi), tb], dim=1).requires_grad_(True)
+    ul, ur = model_fn(pl), model_fn(pr)
+    dl = torch.autograd.grad(ul, pl, grad_outputs=torch.ones_like(ul), create_graph=True)[0][:, 0:1]
+    dr = torch.autograd.grad(ur, pr, grad_outputs=torch.ones_like(ur), create_graph=True)[0][:, 0:1]
+    boundary_loss = torch.tensor(0.0) + lf(ul - ur) + lf(dl - dr)
+    nip = num_initial_points if num_initial_points is not None else max(len(x) // 5, 10)
+    xb = (x_hi - x_lo) * 0.1
+    xi = torch.cat([torch.linspace(x_lo, x_lo + xb, nip // 4), torch.linspace(x_lo + xb, x_hi - xb, nip // 2),
+                    torch.linspace(x_hi - xb, x_hi, nip // 4)]).reshape(-1, 1)
+    ti = torch.zeros_like(xi)
+    ui = model_fn(torch.cat([xi, ti], dim=1))
+    ic = pde.initial_condition
+    kind = ic.get("type", "sine")
+    A, k = ic.get("amplitude", 1.0), ic.get("frequency", 2.0)
+    wn = 2 * torch.pi * k / (x_hi - x_lo)  # heat_equation.py:214-262: the heat IC uses the wave number 2 pi k / L
+    if kind == "sin_exp_decay":
+        target = A * torch.sin(wn * xi) * torch.exp(-(pde.parameters["alpha"] * wn**2) * ti)
+    else:
+        target = A * torch.sin(wn * xi)
+    initial_loss = lf(ui - target)
+    lw = pde.loss_weights
+    if lw:
+        rw, bw, iw = lw.get("pde", lw.get("residual", 1.0)), lw.get("boundary", 10.0), lw.get("initial", 10.0)
+    else:
+        rw, bw, iw = 1.0, 10.0, 10.0
+    total = rw * residual_loss + bw * boundary_loss + iw * initial_loss
+    return {"residual": residual_loss, "boundary": boundary_loss, "initial": initial_loss, "total": total}

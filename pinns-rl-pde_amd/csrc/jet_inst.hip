@@ -1,5 +1,6 @@
 // One translation unit per (time_order, space_order) stream set; the Makefile compiles this file
 // several times with -DPINN_NT=.. -DPINN_NX=.. so the instantiations build in parallel.
+#include "jet_kernel_attn.h"
 #include "jet_kernel_wide.h"
 
 #ifndef PINN_NT
@@ -17,5 +18,13 @@ hipError_t PINN_CAT(launch_jet_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd
 // wide kernel: all K streams LDS-resident, persistent dW accumulators (K * Hmax small enough)
 hipError_t PINN_CAT(launch_jetw_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
   return launch_jet_wide<PINN_NT, PINN_NX>(a, bwd, grid, stream);
+}
+// ResNet kernel (LayerNorm jets; derivative orders <= 2)
+hipError_t PINN_CAT(launch_jetr_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
+  return launch_jet_resnet<PINN_NT, PINN_NX>(a, bwd, grid, stream);
+}
+// attention-as-MLP kernel (LayerNorm + chunked 4x feed-forward)
+hipError_t PINN_CAT(launch_jeta_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
+  return launch_jet_attn<PINN_NT, PINN_NX>(a, bwd, grid, stream);
 }
 }  // namespace pinn

@@ -54,8 +54,14 @@ struct LayerDev {
   float* db;       // nullable
   int in_dim;      // multiple of 8
   int out_dim;     // multiple of 32
+  int ld;          // row stride of W / dW in floats (= in_dim unless this is a column-chunk view of a wider matrix)
   int act;
   float act_param;
+  // LayerNorm that follows this Linear (ResNet / attention); null for the plain-MLP family
+  const float* ln_g;
+  const float* ln_b;
+  float* d_ln_g;
+  float* d_ln_b;
 };
 
 struct NetDev {
@@ -76,6 +82,8 @@ struct NetDev {
   float* db_out;
   int h_last;
   int hmax;  // max feature count over encoding + layers, rounded up to 32
+  int arch;    // PinnArch (selects the kernel family)
+  float ln_eps;
 };
 
 struct KernelArgs {
@@ -144,7 +152,12 @@ __device__ __forceinline__ LayerDev uniform_layer(const LayerDev& s) {
   u.dW = uniform_ptr(s.dW);
   u.db = uniform_ptr(s.db);
   u.in_dim = __builtin_amdgcn_readfirstlane(s.in_dim);
+  u.ld = __builtin_amdgcn_readfirstlane(s.ld);
   u.out_dim = __builtin_amdgcn_readfirstlane(s.out_dim);
+  u.ln_g = uniform_ptr(s.ln_g);
+  u.ln_b = uniform_ptr(s.ln_b);
+  u.d_ln_g = uniform_ptr(s.d_ln_g);
+  u.d_ln_b = uniform_ptr(s.d_ln_b);
   u.act = __builtin_amdgcn_readfirstlane(s.act);
   u.act_param = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s.act_param)));
   return u;
@@ -166,7 +179,7 @@ __device__ __forceinline__ void stage_one(const f32x16 (&v)[NTILE], float* buf, 
 // acc[jt] += W[own rows of tile jt][:] . S[:][n]   (one stream).  Loads run one k-group ahead of the MFMAs.
 template <int NTILE>
 __device__ __forceinline__ void gemm_rows(f32x16 (&acc)[NTILE], const LayerDev& Ly, const float* S, const Lane& L) {
-  const int in = Ly.in_dim;
+  const int in = Ly.in_dim, ld = Ly.ld;
   const float* xcol = S + (4 * L.lh) * kTP + L.ln;
   const float* wrow[NTILE];
   bool on[NTILE];
@@ -174,7 +187,7 @@ __device__ __forceinline__ void gemm_rows(f32x16 (&acc)[NTILE], const LayerDev& 
   for (int jt = 0; jt < NTILE; ++jt) {
     const int ft = L.wave + kWaves * jt;
     on[jt] = ft * 32 < Ly.out_dim;
-    wrow[jt] = Ly.W + (long long)((on[jt] ? ft : 0) * 32 + L.ln) * in + 4 * L.lh;
+    wrow[jt] = Ly.W + (long long)((on[jt] ? ft : 0) * 32 + L.ln) * ld + 4 * L.lh;
   }
   if (!on[0]) return;
   f32x4 wc[NTILE], wn[NTILE];
@@ -205,7 +218,7 @@ __device__ __forceinline__ void gemm_rows(f32x16 (&acc)[NTILE], const LayerDev& 
 // acc[jt] += W[:][own columns of tile jt]^T . Z[:][n]   (one stream; delta-propagation)
 template <int NTILE>
 __device__ __forceinline__ void gemm_cols(f32x16 (&acc)[NTILE], const LayerDev& Ly, const float* Z, const Lane& L) {
-  const int in = Ly.in_dim, out = Ly.out_dim;
+  const int in = Ly.in_dim, out = Ly.out_dim, ld = Ly.ld;
   const float* zcol = Z + (4 * L.lh) * kTP + L.ln;
   const float* wcol[NTILE];
   bool on[NTILE];
@@ -213,14 +226,14 @@ __device__ __forceinline__ void gemm_cols(f32x16 (&acc)[NTILE], const LayerDev& 
   for (int jt = 0; jt < NTILE; ++jt) {
     const int kt = L.wave + kWaves * jt;
     on[jt] = kt * 32 < in;
-    wcol[jt] = Ly.W + (long long)(4 * L.lh) * in + (on[jt] ? kt : 0) * 32 + L.ln;
+    wcol[jt] = Ly.W + (long long)(4 * L.lh) * ld + (on[jt] ? kt : 0) * 32 + L.ln;
   }
   if (!on[0]) return;
   float wc[NTILE][4], wn[NTILE][4], bc[4], bn[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int jt = 0; jt < NTILE; ++jt) wc[jt][i] = wcol[jt][(long long)i * in];
+    for (int jt = 0; jt < NTILE; ++jt) wc[jt][i] = wcol[jt][(long long)i * ld];
     bc[i] = zcol[i * kTP];
   }
   for (int g = 0; g < out; g += 8) {
@@ -228,7 +241,7 @@ __device__ __forceinline__ void gemm_cols(f32x16 (&acc)[NTILE], const LayerDev& 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int jt = 0; jt < NTILE; ++jt) wn[jt][i] = wcol[jt][(long long)(gn + i) * in];
+      for (int jt = 0; jt < NTILE; ++jt) wn[jt][i] = wcol[jt][(long long)(gn + i) * ld];
       bn[i] = zcol[(gn + i) * kTP];
     }
 #pragma unroll
@@ -261,7 +274,7 @@ struct WFrag {
 // lane (j = ln, h) <- W[32 ft + j][8 g + 4 h .. + 3]
 __device__ __forceinline__ void load_wrows(WFrag& wf, const LayerDev& Ly, int ft, const Lane& L) {
   const bool on = ft * 32 < Ly.out_dim;
-  const float* wrow = Ly.W + (long long)((on ? ft : 0) * 32 + L.ln) * Ly.in_dim + 4 * L.lh;
+  const float* wrow = Ly.W + (long long)((on ? ft : 0) * 32 + L.ln) * Ly.ld + 4 * L.lh;
 #pragma unroll
   for (int g = 0; g < kMaxG; ++g)
     if (g * 8 < Ly.in_dim) wf.g[g] = *reinterpret_cast<const f32x4*>(wrow + 8 * g);
@@ -270,12 +283,12 @@ __device__ __forceinline__ void load_wrows(WFrag& wf, const LayerDev& Ly, int ft
 // lane (k = ln, h) <- W[8 g + 4 h + i][32 kt + k], i = 0..3
 __device__ __forceinline__ void load_wcols(WFrag& wf, const LayerDev& Ly, int kt, const Lane& L) {
   const bool on = kt * 32 < Ly.in_dim;
-  const float* wcol = Ly.W + (long long)(4 * L.lh) * Ly.in_dim + (on ? kt : 0) * 32 + L.ln;
+  const float* wcol = Ly.W + (long long)(4 * L.lh) * Ly.ld + (on ? kt : 0) * 32 + L.ln;
 #pragma unroll
   for (int g = 0; g < kMaxG; ++g) {
     if (g * 8 < Ly.out_dim) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wf.g[g][i] = wcol[(long long)(8 * g + i) * Ly.in_dim];
+      for (int i = 0; i < 4; ++i) wf.g[g][i] = wcol[(long long)(8 * g + i) * Ly.ld];
     }
   }
 }
@@ -562,7 +575,7 @@ template <int NKT>
 struct PendingDW {
   f32x16 acc[NKT];
   float* base;  // dW + (32 ft + 4 lh) * in_dim + ln   (row offset of register r added at issue)
-  int in_dim;
+  int in_dim;   // row stride of dW
   int na;       // active k-tiles
   bool live;
 };
@@ -914,8 +927,8 @@ __global__ __launch_bounds__(kThreads, OCC) void jet_kernel(const KernelArgs a) 
           if (Ly.dW && L.wave * 32 < Ly.out_dim) {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) pend.acc[kt] = dacc[0][kt];
-            pend.base = Ly.dW + (long long)(L.wave * 32 + 4 * L.lh) * Ly.in_dim + L.ln;
-            pend.in_dim = Ly.in_dim;
+            pend.base = Ly.dW + (long long)(L.wave * 32 + 4 * L.lh) * Ly.ld + L.ln;
+            pend.in_dim = Ly.ld;
             pend.na = (Ly.in_dim + 31) >> 5;
             pend.live = true;
             // Measured: draining behind later MFMA work does not help — atomics share the in-order vmcnt queue
@@ -933,7 +946,7 @@ __global__ __launch_bounds__(kThreads, OCC) void jet_kernel(const KernelArgs a) 
                 if (kt * 32 < Ly.in_dim) {
 #pragma unroll
                   for (int r = 0; r < 16; ++r)
-                    atomicAdd(Ly.dW + (long long)(ft * 32 + acc_row(r, L.lh)) * Ly.in_dim + kt * 32 + L.ln,
+                    atomicAdd(Ly.dW + (long long)(ft * 32 + acc_row(r, L.lh)) * Ly.ld + kt * 32 + L.ln,
                               dacc[jt][kt][r]);
                 }
               }

@@ -164,12 +164,12 @@ __device__ __forceinline__ void load_bias(f32x4 (&bias)[4], const LayerDev& Ly, 
 
 __device__ __forceinline__ void flush_rows(const f32x16 (&dacc)[4], const LayerDev& Ly, const Lane& L) {
   if (!Ly.dW || L.wave * 32 >= Ly.out_dim) return;
-  float* base = Ly.dW + (long long)(L.wave * 32 + 4 * L.lh) * Ly.in_dim + L.ln;
+  float* base = Ly.dW + (long long)(L.wave * 32 + 4 * L.lh) * Ly.ld + L.ln;
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     if (kt * 32 < Ly.in_dim) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(base + (long long)((r & 3) + 8 * (r >> 2)) * Ly.in_dim + kt * 32, dacc[kt][r]);
+      for (int r = 0; r < 16; ++r) atomicAdd(base + (long long)((r & 3) + 8 * (r >> 2)) * Ly.ld + kt * 32, dacc[kt][r]);
     }
   }
 }

@@ -7,14 +7,22 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "jet_kernel_attn.h"
 #include "jet_kernel_wide.h"
 
 namespace pinn {
 #define PINN_DECL(nt, nx)                                                               \
   hipError_t launch_jet_##nt##_##nx(const KernelArgs&, bool, int, int, hipStream_t); \
-  hipError_t launch_jetw_##nt##_##nx(const KernelArgs&, bool, int, hipStream_t);
-#ifdef PINN_DEV /* developer build: stream set (1, 2) only */
-PINN_DECL(1, 2)
+  hipError_t launch_jetw_##nt##_##nx(const KernelArgs&, bool, int, hipStream_t);      \
+  hipError_t launch_jetr_##nt##_##nx(const KernelArgs&, bool, int, hipStream_t);      \
+  hipError_t launch_jeta_##nt##_##nx(const KernelArgs&, bool, int, hipStream_t);
+#ifdef PINN_DEV /* developer build: ONE stream set, -DPINN_DEV_NT / -DPINN_DEV_NX (default 1, 2) */
+#ifndef PINN_DEV_NT
+#define PINN_DEV_NT 1
+#define PINN_DEV_NX 2
+#endif
+#define PINN_DECL2(a, b) PINN_DECL(a, b)
+PINN_DECL2(PINN_DEV_NT, PINN_DEV_NX)
 #else
 PINN_DECL(0, 0)
 PINN_DECL(1, 0)
@@ -98,6 +106,110 @@ static int build_net(const PinnNetDesc* d, const float* const* w, float* const* 
     n.enc_param = par;
     first_mfma = 1;
     wbase = 0;
+  } else if (d->arch == PINN_ARCH_RESNET) {
+    // state_dict order (resnet.py:114-127): input_layer.{weight,bias}; per block layers.0 (Linear), layers.1 (LN1),
+    // layers.4 (Linear), layers.5 (LN2) — weight then bias each; output_layer.{weight,bias}
+    const int nb = d->num_blocks;
+    if (nb < 1 || 2 * nb > kMaxLayers || d->num_linear != 2 * nb + 2) return fail(PINN_ERR_BAD_DESC, "resnet: num_blocks=%d / num_linear=%d", nb, d->num_linear);
+    const int H = d->widths[0];
+    if (H % 32 || H <= 0 || H > 256) return fail(PINN_ERR_UNSUPPORTED, "resnet width %d must be a multiple of 32 in [32,256]", H);
+    n.arch = PINN_ARCH_RESNET;
+    n.ln_eps = d->ln_eps > 0.0f ? d->ln_eps : 1e-5f;
+    n.enc = ENC_LINEAR;
+    n.enc_out = H;
+    n.encW = w[0];
+    n.encb = w[1];
+    n.d_encW = g ? g[0] : nullptr;
+    n.d_encb = g ? g[1] : nullptr;
+    n.enc_act = act;
+    n.enc_param = par;
+    n.n_layers = 2 * nb;
+    for (int b = 0; b < nb; ++b) {
+      for (int half = 0; half < 2; ++half) {
+        const int base = 2 + 8 * b + 4 * half;
+        LayerDev& L = n.layer[2 * b + half];
+        L.W = w[base];
+        L.b = w[base + 1];
+        L.ln_g = w[base + 2];
+        L.ln_b = w[base + 3];
+        L.dW = g ? g[base] : nullptr;
+        L.db = g ? g[base + 1] : nullptr;
+        L.d_ln_g = g ? g[base + 2] : nullptr;
+        L.d_ln_b = g ? g[base + 3] : nullptr;
+        L.in_dim = H;
+        L.ld = H;
+        L.out_dim = H;
+        L.act = act;
+        L.act_param = par;
+        if (!L.W || !L.b || !L.ln_g || !L.ln_b) return fail(PINN_ERR_BAD_DESC, "null weight pointer in resnet block %d", b);
+        if ((reinterpret_cast<uintptr_t>(L.W) & 15) || (reinterpret_cast<uintptr_t>(L.b) & 15))
+          return fail(PINN_ERR_MISALIGNED, "resnet block %d weights are not 16-byte aligned", b);
+      }
+    }
+    const int io = 2 + 8 * nb;
+    n.w_out = w[io];
+    n.b_out = w[io + 1];
+    n.dw_out = g ? g[io] : nullptr;
+    n.db_out = g ? g[io + 1] : nullptr;
+    n.h_last = H;
+    n.hmax = H;
+    if (!n.w_out || !n.b_out || !n.encW || !n.encb) return fail(PINN_ERR_BAD_DESC, "null weight pointer");
+    *out = n;
+    return PINN_OK;
+  } else if (d->arch == PINN_ARCH_ATTENTION) {
+    // state_dict order (attention.py:136-156): input_proj.{w,b}; per layer: query, key, value, proj (w,b each),
+    // layer_norm (LN_a), net.0, net.3, layer_norm (LN_f); output_proj.{w,b}.  query/key are dead (sequence length 1).
+    const int nl = d->num_blocks;
+    if (nl < 1 || 4 * nl > kMaxLayers || d->num_linear != 2) return fail(PINN_ERR_BAD_DESC, "attention: num_blocks=%d / num_linear=%d", nl, d->num_linear);
+    const int H = d->widths[0];
+    if (H % 32 || H <= 0 || H > 256) return fail(PINN_ERR_UNSUPPORTED, "attention width %d must be a multiple of 32 in [32,256]", H);
+    n.arch = PINN_ARCH_ATTENTION;
+    n.ln_eps = d->ln_eps > 0.0f ? d->ln_eps : 1e-5f;
+    n.enc = ENC_LINEAR;
+    n.enc_out = H;
+    n.encW = w[0];
+    n.encb = w[1];
+    n.d_encW = g ? g[0] : nullptr;
+    n.d_encb = g ? g[1] : nullptr;
+    n.enc_act = act;
+    n.enc_param = par;
+    n.n_layers = 4 * nl;
+    for (int l = 0; l < nl; ++l) {
+      const int base = 2 + 16 * l;
+      struct { int wi, lni, in, out; } e[4] = {{base + 4, -1, H, H}, {base + 6, base + 8, H, H},
+                                                {base + 10, -1, H, 4 * H}, {base + 12, base + 14, 4 * H, H}};
+      for (int q = 0; q < 4; ++q) {
+        LayerDev& L = n.layer[4 * l + q];
+        L.W = w[e[q].wi];
+        L.b = w[e[q].wi + 1];
+        L.dW = g ? g[e[q].wi] : nullptr;
+        L.db = g ? g[e[q].wi + 1] : nullptr;
+        if (e[q].lni >= 0) {
+          L.ln_g = w[e[q].lni];
+          L.ln_b = w[e[q].lni + 1];
+          L.d_ln_g = g ? g[e[q].lni] : nullptr;
+          L.d_ln_b = g ? g[e[q].lni + 1] : nullptr;
+        }
+        L.in_dim = e[q].in;
+        L.out_dim = e[q].out;
+        L.ld = e[q].in;
+        L.act = PINN_ACT_GELU;
+        L.act_param = 0.0f;
+        if (!L.W || !L.b) return fail(PINN_ERR_BAD_DESC, "null weight pointer in attention layer %d", l);
+        if ((reinterpret_cast<uintptr_t>(L.W) & 15) || (reinterpret_cast<uintptr_t>(L.b) & 15))
+          return fail(PINN_ERR_MISALIGNED, "attention layer %d weights are not 16-byte aligned", l);
+      }
+    }
+    const int io = 2 + 16 * nl;
+    n.w_out = w[io];
+    n.b_out = w[io + 1];
+    n.dw_out = g ? g[io] : nullptr;
+    n.db_out = g ? g[io + 1] : nullptr;
+    n.h_last = H;
+    n.hmax = H;
+    if (!n.w_out || !n.b_out || !n.encW || !n.encb) return fail(PINN_ERR_BAD_DESC, "null weight pointer");
+    *out = n;
+    return PINN_OK;
   } else {
     return fail(PINN_ERR_UNSUPPORTED, "architecture id %d has no fused kernel yet", d->arch);
   }
@@ -114,6 +226,7 @@ static int build_net(const PinnNetDesc* d, const float* const* w, float* const* 
     L.dW = g ? g[wbase + 2 * i] : nullptr;
     L.db = g ? g[wbase + 2 * i + 1] : nullptr;
     L.in_dim = prev;
+    L.ld = prev;
     L.out_dim = wd;
     L.act = act;
     L.act_param = par;
@@ -135,6 +248,12 @@ static int build_net(const PinnNetDesc* d, const float* const* w, float* const* 
   return PINN_OK;
 }
 
+static long long tape_floats_per_wg(const NetDev& n, int K, int ntile) {
+  if (n.arch == PINN_ARCH_RESNET) return jet_resnet_tape_floats_per_wg(K, n.n_layers / 2, ntile);
+  if (n.arch == PINN_ARCH_ATTENTION) return jet_attn_tape_floats_per_wg(K, n.n_layers / 4, ntile);
+  return jet_tape_floats_per_wg(K, n.n_layers, ntile);
+}
+
 static int check_orders(int nt, int nx) {
   if (nt < 0 || nt > 2) return fail(PINN_ERR_BAD_ORDER, "Temporal derivative order %d is not supported. Maximum order is 2.", nt);
   if (nx < 0 || nx > 4) return fail(PINN_ERR_BAD_ORDER, "Spatial derivative order %d is not supported. Maximum order is 4.", nx);
@@ -150,11 +269,15 @@ static bool pick_streams(int nt, int nx, int* knt, int* knx) {
 }
 
 static hipError_t dispatch(int nt, int nx, const KernelArgs& a, bool bwd, int grid, int occ, bool wide, hipStream_t st) {
-#define PINN_CASE(NT_, NX_)                                                                   \
-  if (nt == NT_ && nx == NX_)                                                                 \
-    return wide ? launch_jetw_##NT_##_##NX_(a, bwd, grid, st) : launch_jet_##NT_##_##NX_(a, bwd, grid, occ, st);
+#define PINN_CASE(NT_, NX_)                                                                    \
+  if (nt == NT_ && nx == NX_) {                                                                \
+    if (a.net.arch == PINN_ARCH_RESNET) return launch_jetr_##NT_##_##NX_(a, bwd, grid, st);    \
+    if (a.net.arch == PINN_ARCH_ATTENTION) return launch_jeta_##NT_##_##NX_(a, bwd, grid, st); \
+    return wide ? launch_jetw_##NT_##_##NX_(a, bwd, grid, st) : launch_jet_##NT_##_##NX_(a, bwd, grid, occ, st); \
+  }
 #ifdef PINN_DEV
-  PINN_CASE(1, 2)
+#define PINN_CASE2(a, b) PINN_CASE(a, b)
+  PINN_CASE2(PINN_DEV_NT, PINN_DEV_NX)
 #else
   PINN_CASE(0, 0) PINN_CASE(1, 0) PINN_CASE(1, 1) PINN_CASE(1, 2) PINN_CASE(1, 3) PINN_CASE(1, 4) PINN_CASE(2, 0) PINN_CASE(2, 2)
 #endif
@@ -185,13 +308,15 @@ static bool use_wide(const NetDev& n, int K, bool bwd) {
 
 static int grid_for(const NetDev& n, int K, long long N, bool bwd, size_t* lds_out, int* occ_out = nullptr,
                     bool* wide_out = nullptr) {
-  const bool wide = use_wide(n, K, bwd);
+  const bool resnet = n.arch == PINN_ARCH_RESNET || n.arch == PINN_ARCH_ATTENTION;  // LayerNorm kernels
+  const bool wide = !resnet && use_wide(n, K, bwd);
   if (wide_out) *wide_out = wide;
-  const size_t lds = wide ? jet_wide_lds_bytes(K, n.hmax, bwd) : jet_lds_bytes(K, n.hmax, bwd);
+  const size_t lds = resnet ? jet_resnet_lds_bytes(K, n.hmax, bwd)
+                            : (wide ? jet_wide_lds_bytes(K, n.hmax, bwd) : jet_lds_bytes(K, n.hmax, bwd));
   if (lds_out) *lds_out = lds;
   if (lds > kLdsLimit) return 0;
   const long long ntiles = (N + kT - 1) / kT;
-  const int per_cu = wide ? 1 : occupancy_for(n, lds, bwd);
+  const int per_cu = (wide || resnet) ? 1 : occupancy_for(n, lds, bwd);
   if (occ_out) *occ_out = per_cu;
   long long g = (long long)num_cus() * per_cu;
   if (g > ntiles) g = ntiles;
@@ -245,7 +370,7 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
   a.stamps = g_stamps;
   if (bwd) {
     const int ntile = a.net.hmax > 128 ? 2 : 1;
-    a.tape_stride = jet_tape_floats_per_wg(K, a.net.n_layers, ntile);
+    a.tape_stride = tape_floats_per_wg(a.net, K, ntile);
     const size_t need = (size_t)a.tape_stride * sizeof(float) * grid;
     if (need > 0 && (!workspace || ws_bytes < need))
       return fail(PINN_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
@@ -253,6 +378,7 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
     a.tape = static_cast<float*>(workspace);
   }
   const hipError_t e = dispatch(knt, knx, a, bwd, grid, occ, wide, static_cast<hipStream_t>(stream));
+  if (e == hipErrorNotSupported) return fail(PINN_ERR_UNSUPPORTED, "derivative orders above 2 through LayerNorm (nt=%d, nx=%d)", knt, knx);
   if (e != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)e, hipGetErrorString(e));
   return PINN_OK;
 }
@@ -299,7 +425,7 @@ size_t pinn_workspace_bytes(const PinnNetDesc* net, int64_t N, int32_t time_orde
   const int K = 1 + time_order + space_order;
   const int grid = grid_for(n, K, N, true, nullptr);
   const int ntile = n.hmax > 128 ? 2 : 1;
-  return (size_t)jet_tape_floats_per_wg(K, n.n_layers, ntile) * sizeof(float) * (size_t)grid;
+  return (size_t)tape_floats_per_wg(n, K, ntile) * sizeof(float) * (size_t)grid;
 }
 
 int pinn_jet_forward(const PinnNetDesc* net, const float* const* weights, const float* x, const float* t, int64_t N,

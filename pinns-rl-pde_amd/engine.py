@@ -99,6 +99,11 @@ class NetProgram:
         widths = [d.widths[i] for i in range(d.num_linear)]
         if self.arch == "fourier":
             prev, total = 2 * d.mapping_size, 2 * d.input_dim * d.mapping_size
+        elif self.arch == "resnet":
+            prev, total = d.input_dim, 0  # widths = [H] * (1 + 2 * blocks) + [out]: every Linear is listed
+        elif self.arch == "attention":  # live Linears only: in, per layer value + proj + 2 x (H x 4H), out
+            H = widths[0]
+            return 2 * (d.input_dim * H + d.num_blocks * (2 * H * H + 8 * H * H) + H * widths[-1])
         else:
             prev, total = d.input_dim, 0
         for w in widths:

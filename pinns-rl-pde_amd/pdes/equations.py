@@ -133,6 +133,87 @@ class HeatEquation(PDEBase):
                 return lambda x, t: A * torch.prod(torch.sin(wn * x), dim=1, keepdim=True)
         return super()._create_boundary_condition(bc_type, params)
 
+    def _num_points(self, key: str, divisor: int, n: int) -> int:
+        tr = self.config.training
+        if tr is None:
+            return max(n // divisor, 10)
+        if isinstance(tr, dict):
+            return tr.get(key, tr.get("num_collocation_points", n) // divisor)
+        return getattr(tr, key, tr.num_collocation_points // divisor)
+
+    def compute_loss(self, model, x, t, n_total=None, aux_scale: float = 1.0):
+        """heat_equation.py:375-623 — periodic BC (u and du/dx match at the two ends, points clustered near t = 0),
+        IC points clustered near the ends, optional finite-difference smoothness term.  The boundary du/dx that the
+        reference obtains with `autograd.grad(create_graph=True)` is the x-stream of the jet kernel."""
+        dev = self.device
+        residual_loss = self._residual_loss(model, x, t, n_total)
+        nbp = self._num_points("num_boundary_points", 10, len(x))
+        t_max = self.config.time_domain[1]
+        t_early = t_max * 0.01
+        n_early = max(nbp // 4, 1)
+        tb = torch.cat([torch.linspace(0, t_early, n_early, device=dev),
+                        torch.linspace(t_early, t_max, nbp - n_early, device=dev)]).reshape(-1, 1)
+        boundary_loss = torch.tensor(0.0, device=dev)
+        if self.dimension == 1:
+            x_lo, x_hi = self.config.domain[0]
+            jl = model.jets(torch.full((nbp, 1), x_lo, device=dev), tb, 1, 1)  # streams: u, u_t, u_x
+            jr = model.jets(torch.full((nbp, 1), x_hi, device=dev), tb, 1, 1)
+            boundary_loss = boundary_loss + self._apply_loss_fn((jl[0] - jr[0]).unsqueeze(1))
+            boundary_loss = boundary_loss + self._apply_loss_fn((jl[2] - jr[2]).unsqueeze(1))
+        else:
+            per_axis = max(nbp // (2 * self.dimension), 1)
+            for axis in range(self.dimension):
+                free = torch.empty(per_axis, self.dimension, device=dev)
+                for d in range(self.dimension):
+                    lo, hi = self.config.domain[d]
+                    free[:, d] = torch.rand(per_axis, device=dev) * (hi - lo) + lo
+                ta = torch.rand(per_axis, 1, device=dev) * (t_max - self.config.time_domain[0]) + self.config.time_domain[0]
+                cmin, cmax = free.clone(), free.clone()
+                cmin[:, axis], cmax[:, axis] = self.config.domain[axis]
+                boundary_loss = boundary_loss + self._apply_loss_fn(
+                    model(torch.cat([cmin, ta], dim=1)) - model(torch.cat([cmax, ta], dim=1)))
+        nip = self._num_points("num_initial_points", 5, len(x))
+        if self.dimension == 1:
+            x_lo, x_hi = self.config.domain[0]
+            xb = (x_hi - x_lo) * 0.1
+            xi = torch.cat([torch.linspace(x_lo, x_lo + xb, nip // 4, device=dev),
+                            torch.linspace(x_lo + xb, x_hi - xb, nip // 2, device=dev),
+                            torch.linspace(x_hi - xb, x_hi, nip // 4, device=dev)]).reshape(-1, 1)
+        else:
+            xi = torch.empty(nip, self.dimension, device=dev)
+            for d in range(self.dimension):
+                lo, hi = self.config.domain[d]
+                xi[:, d] = torch.rand(nip, device=dev) * (hi - lo) + lo
+        ti = torch.zeros(xi.shape[0], 1, device=dev)
+        ui = model(torch.cat([xi, ti], dim=1))
+        if "initial" in self.boundary_conditions:
+            target = self.boundary_conditions["initial"](xi, ti)
+        else:
+            k = self.config.initial_condition.get("frequency", 2.0)
+            target = torch.ones(xi.shape[0], 1, device=dev)
+            for d in range(self.dimension):
+                target = target * torch.sin(k * torch.pi * xi[:, d : d + 1])
+        initial_loss = self._apply_loss_fn(ui - target)
+        lw = self._loss_weights()
+        smoothness_loss = torch.tensor(0.0, device=dev)
+        if lw and lw.get("smoothness", 0.0) > 0:
+            smoothness_loss = self._compute_smoothness_loss(model, x, t)
+        return self._compose_losses(residual_loss, boundary_loss, initial_loss, smoothness_loss,
+                                    self._compute_data_loss(model), aux_scale)
+
+    def _compute_smoothness_loss(self, model, x, t):  # heat_equation.py:625-650
+        eps = 1e-4
+        x, t = x.detach(), t.detach()
+        uc = model(torch.cat([x, t], dim=1))
+        out = torch.tensor(0.0, device=self.device)
+        for d in range(self.dimension):
+            xp, xm = x.clone(), x.clone()
+            xp[:, d : d + 1] = torch.clamp(x[:, d : d + 1] + eps, self.domain[d][0], self.domain[d][1])
+            xm[:, d : d + 1] = torch.clamp(x[:, d : d + 1] - eps, self.domain[d][0], self.domain[d][1])
+            up, um = model(torch.cat([xp, t], dim=1)), model(torch.cat([xm, t], dim=1))
+            out = out + torch.mean(torch.abs((up - uc) / eps)) + torch.mean(torch.abs((uc - um) / eps))
+        return out
+
     def exact_solution(self, x, t):  # heat_equation.py:112-196 (1-D / product forms)
         es = getattr(self.config, "exact_solution", None) or {}
         src = es if es else (getattr(self.config, "initial_condition", None) or {})

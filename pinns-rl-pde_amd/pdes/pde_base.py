@@ -70,6 +70,25 @@ class PDEBase:
 
     KIND: str = ""  # name in pinnrl_amd._lib.PDE
 
+    @staticmethod
+    def create(pde_type: str, config: Optional[PDEConfig] = None, **kwargs) -> "PDEBase":
+        """Factory by type name (pde_base.py:55-130): 'heat', 'burgers', 'allen_cahn', ... or '<name>_equation'."""
+        from . import _BY_TYPE
+
+        key = pde_type.lower().replace("_equation", "").replace("equation", "").strip("_")
+        if key not in _BY_TYPE:
+            raise ValueError(f"Could not find PDE implementation for type: {pde_type}")
+        if config is None:
+            config = PDEConfig(
+                name=kwargs.pop("name", _BY_TYPE[key].__name__), domain=kwargs.pop("domain", [(0.0, 1.0)]),
+                time_domain=kwargs.pop("time_domain", (0.0, 1.0)), parameters=kwargs.pop("parameters", {}),
+                boundary_conditions=kwargs.pop("boundary_conditions", {}),
+                initial_condition=kwargs.pop("initial_condition", {}), exact_solution=kwargs.pop("exact_solution", {}),
+                dimension=kwargs.pop("dimension", 1), input_dim=kwargs.pop("input_dim", None),
+                output_dim=kwargs.pop("output_dim", None), architecture=kwargs.pop("architecture", None),
+                device=kwargs.pop("device", None), training=kwargs.pop("training", None))
+        return _BY_TYPE[key](config=config, **kwargs)
+
     # ---------------------------------------------------------------- construction (pde_base.py:132-239)
     def __init__(self, config: PDEConfig, rl_agent=None):
         self.config = config
@@ -514,6 +533,10 @@ class PDEBase:
         initial_loss = self._apply_loss_fn(ui - target)
         data_loss = self._compute_data_loss(model)
         smoothness_loss = torch.tensor(0.0, device=dev)
+        return self._compose_losses(residual_loss, boundary_loss, initial_loss, smoothness_loss, data_loss, aux_scale)
+
+    def _compose_losses(self, residual_loss, boundary_loss, initial_loss, smoothness_loss, data_loss, aux_scale=1.0):
+        """The weighting / mode gating tail shared by every `compute_loss` (pde_base.py:1168-1235, heat_equation.py:543-623)."""
         lw_obj = self._loss_weights()
         smoothness_weight = lw_obj.get("smoothness", 0.0) if lw_obj else 0.0
         losses = {"residual": residual_loss, "boundary": boundary_loss, "initial": initial_loss,

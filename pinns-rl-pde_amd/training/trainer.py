@@ -160,7 +160,7 @@ class PDETrainer:
             self.optimizer.zero_grad()
             losses = self._losses(x, t)
             losses["total"].backward()
-            self._sync_grads()
+            self._sync_grads(losses)
             captured["losses"] = losses
             return losses["total"]
 
@@ -174,9 +174,20 @@ class PDETrainer:
             return _D.sharded_compute_loss(self.pde, self.model, x, t, self.process_group)
         return self.pde.compute_loss(self.model, x, t)
 
-    def _sync_grads(self):
-        if self.process_group is not None:
-            _D.all_reduce_gradients(self._collect_optimizable_params(), self.process_group)
+    def _sync_grads(self, losses=None):
+        """ONE all-reduce of [gradients || residual loss]; the reduced (global) residual replaces the local shard's."""
+        if self.process_group is None:
+            return
+        scalars = [losses["residual"]] if losses is not None else None
+        red = _D.all_reduce_gradients(self._collect_optimizable_params(), self.process_group, scalars=scalars)
+        if red is not None and losses is not None:
+            world = torch.distributed.get_world_size(self.process_group)
+            local = losses["residual"].detach()
+            losses["residual"] = red[0]
+            # local total = rw * local_residual + (aux terms) / world  ->  global total (for logging only)
+            lw = self.pde._loss_weights() if hasattr(self.pde, "_loss_weights") else None
+            rw = (lw.get("pde", lw.get("residual", 1.0)) if lw else 1.0)
+            losses["total"] = (losses["total"].detach() - rw * local) * world + rw * red[0]
 
     def _adaptive_total(self, losses):
         """trainer.py:586-684 without the printing: reweight residual/boundary/initial (+ smoothness)."""
@@ -217,7 +228,7 @@ class PDETrainer:
         if self.use_adaptive_weights and self.config.training.mode != "data_only":
             losses["total"] = self._adaptive_total(losses)
         losses["total"].backward()
-        self._sync_grads()
+        self._sync_grads(losses)
         gc = self.config.training.gradient_clipping
         if gc > 0:
             nn.utils.clip_grad_norm_(self.model.parameters(), gc)

@@ -5,7 +5,7 @@ import torch
 import pinnrl_amd  # noqa: F401
 from pinnrl_amd import engine as E
 
-FUSED_ARCHS = ("fourier", "feedforward", "siren")
+FUSED_ARCHS = ("fourier", "feedforward", "siren", "resnet", "attention")
 
 
 def program_from_spec(spec, sd, device):
@@ -23,6 +23,13 @@ def program_from_spec(spec, sd, device):
     if spec.architecture == "siren":
         widths = list(spec.dims()) + [spec.output_dim]
         return E.NetProgram("siren", "sin", spec.input_dim, widths, tensors, trainable, omega_0=spec.omega_0), names
+    if spec.architecture == "resnet":
+        nb = spec.num_blocks if spec.num_blocks is not None else spec.num_layers
+        widths = [spec.hidden_dim] * (1 + 2 * nb) + [spec.output_dim]
+        return E.NetProgram("resnet", spec.activation, spec.input_dim, widths, tensors, trainable, num_blocks=nb), names
+    if spec.architecture == "attention":
+        return E.NetProgram("attention", spec.activation, spec.input_dim, [spec.hidden_dim, spec.output_dim], tensors,
+                            trainable, num_blocks=spec.num_layers), names
     raise NotImplementedError(spec.architecture)
 
 

@@ -317,3 +317,228 @@ def pde_residual(name: str, p: Mapping, j: List[Tensor], x0: Tensor, NT: int, NX
         d[0], d[2] = gl * torch.cos(u), one
         return T(2) + gl * torch.sin(u), d
     raise ValueError(name)
+
+
+# ----------------------------------------------------------------------------
+# LayerNorm reverse + the ResNet sweep (mirrors csrc/jet_kernel_resnet.h)
+# ----------------------------------------------------------------------------
+def ln_stats(z: List[Tensor], eps: float, NT: int, NX: int):
+    """Centred streams and the per-point statistics (r, v1/v2 per direction)."""
+    c = [s - s.mean(-1, keepdim=True) for s in z]
+    r = ((c[0] * c[0]).mean(-1, keepdim=True) + eps) ** -0.5
+    zero = torch.zeros_like(r)
+
+    def mom(first, second):
+        v1 = 2 * (c[0] * first).mean(-1, keepdim=True) if first is not None else zero
+        v2 = 2 * (first * first + c[0] * second).mean(-1, keepdim=True) if second is not None else zero
+        return v1, v2
+
+    t1 = c[1] if NT >= 1 else None
+    t2 = c[2] if NT >= 2 else None
+    x1 = c[1 + NT] if NX >= 1 else None
+    x2 = c[2 + NT] if NX >= 2 else None
+    return c, r, mom(t1, t2), mom(x1, x2)
+
+
+def _ln_yhat(c, r, vt, vx, NT, NX):
+    def d(first, second, v1, v2):
+        r1 = -0.5 * r**3 * v1
+        r2 = 0.75 * r**5 * v1 * v1 - 0.5 * r**3 * v2
+        out = []
+        if first is not None:
+            out.append(first * r + c[0] * r1)
+        if second is not None:
+            out.append(second * r + 2 * first * r1 + c[0] * r2)
+        return out
+
+    y = [c[0] * r]
+    y += d(c[1] if NT >= 1 else None, c[2] if NT >= 2 else None, *vt)
+    y += d(c[1 + NT] if NX >= 1 else None, c[2 + NT] if NX >= 2 else None, *vx)
+    return y
+
+
+def ln_fwd2(z, gamma, beta, eps, NT, NX):
+    c, r, vt, vx = ln_stats(z, eps, NT, NX)
+    y = _ln_yhat(c, r, vt, vx, NT, NX)
+    return [y[0] * gamma + beta] + [v * gamma for v in y[1:]]
+
+
+def ln_bwd(z, yb, gamma, eps, NT, NX):
+    """Returns (zbar streams, dgamma, dbeta) — the algorithm of ln_backward() in jet_kernel_resnet.h."""
+    K = 1 + NT + NX
+    H = z[0].shape[-1]
+    c, r, (v1t, v2t), (v1x, v2x) = ln_stats(z, eps, NT, NX)
+    yhat = _ln_yhat(c, r, (v1t, v2t), (v1x, v2x), NT, NX)
+    dgamma = sum((yb[s] * yhat[s]).sum(0) for s in range(K))
+    dbeta = yb[0].sum(0)
+    hb = [gamma * yb[s] for s in range(K)]
+    r3, r5, r2_ = r**3, r**5, r * r
+    S = lambda v: v.sum(-1, keepdim=True)  # noqa: E731
+    q0 = S(hb[0] * c[0])
+    q1t = q2t = q1x = q2x = torch.zeros_like(r)
+    if NT >= 1:
+        q0 = q0 + S(hb[1] * c[1]); q1t = S(hb[1] * c[0])
+    if NT >= 2:
+        q0 = q0 + S(hb[2] * c[2]); q1t = q1t + S(2 * hb[2] * c[1]); q2t = S(hb[2] * c[0])
+    if NX >= 1:
+        q0 = q0 + S(hb[1 + NT] * c[1 + NT]); q1x = S(hb[1 + NT] * c[0])
+    if NX >= 2:
+        q0 = q0 + S(hb[2 + NT] * c[2 + NT]); q1x = q1x + S(2 * hb[2 + NT] * c[1 + NT]); q2x = S(hb[2 + NT] * c[0])
+    r1t, r1x = -0.5 * r3 * v1t, -0.5 * r3 * v1x
+    r2t = 0.75 * r5 * v1t * v1t - 0.5 * r3 * v2t
+    r2x = 0.75 * r5 * v1x * v1x - 0.5 * r3 * v2x
+    v2bt, v2bx = -0.5 * r3 * q2t, -0.5 * r3 * q2x
+    v1bt = -0.5 * r3 * q1t + 1.5 * r5 * v1t * q2t
+    v1bx = -0.5 * r3 * q1x + 1.5 * r5 * v1x * q2x
+    rtot = (q0 + q1t * (-1.5 * r2_ * v1t) + q2t * (3.75 * r2_ * r2_ * v1t * v1t - 1.5 * r2_ * v2t)
+            + q1x * (-1.5 * r2_ * v1x) + q2x * (3.75 * r2_ * r2_ * v1x * v1x - 1.5 * r2_ * v2x))
+    vb = rtot * (-0.5 * r3)
+    k2 = 2.0 / H
+    cb = [None] * K
+    cb[0] = hb[0] * r + vb * k2 * c[0]
+    if NT >= 1:
+        cb[0] = cb[0] + hb[1] * r1t + v1bt * k2 * c[1]
+        cb[1] = hb[1] * r + v1bt * k2 * c[0]
+    if NT >= 2:
+        cb[0] = cb[0] + hb[2] * r2t + v2bt * k2 * c[2]
+        cb[1] = cb[1] + 2 * hb[2] * r1t + 2 * v2bt * k2 * c[1]
+        cb[2] = hb[2] * r + v2bt * k2 * c[0]
+    if NX >= 1:
+        cb[0] = cb[0] + hb[1 + NT] * r1x + v1bx * k2 * c[1 + NT]
+        cb[1 + NT] = hb[1 + NT] * r + v1bx * k2 * c[0]
+    if NX >= 2:
+        cb[0] = cb[0] + hb[2 + NT] * r2x + v2bx * k2 * c[2 + NT]
+        cb[1 + NT] = cb[1 + NT] + 2 * hb[2 + NT] * r1x + 2 * v2bx * k2 * c[1 + NT]
+        cb[2 + NT] = hb[2 + NT] * r + v2bx * k2 * c[0]
+    zb = [v - v.mean(-1, keepdim=True) for v in cb]
+    return zb, dgamma, dbeta
+
+
+def resnet_jets_forward(spec, sd, inp, NT, NX, eps=1e-5):
+    K = 1 + NT + NX
+    nb = spec.num_blocks if spec.num_blocks is not None else spec.num_layers
+    act = spec.activation
+    a = input_streams(inp, NT, NX)
+    Wi, bi = sd["model.input_layer.weight"], sd["model.input_layer.bias"]
+    z0 = [a[0] @ Wi.T + bi] + [a[s] @ Wi.T for s in range(1, K)]
+    h = act_fwd(act, 0.0, z0, NT, NX)
+    tape = {"inp_streams": a, "z0": z0, "blocks": []}
+    for b in range(nb):
+        p = f"model.blocks.{b}.layers."
+        W1, b1, g1, be1 = sd[p + "0.weight"], sd[p + "0.bias"], sd[p + "1.weight"], sd[p + "1.bias"]
+        W2, b2, g2, be2 = sd[p + "4.weight"], sd[p + "4.bias"], sd[p + "5.weight"], sd[p + "5.bias"]
+        z1 = [h[0] @ W1.T + b1] + [h[s] @ W1.T for s in range(1, K)]
+        y1 = ln_fwd2(z1, g1, be1, eps, NT, NX)
+        a1 = act_fwd(act, 0.0, y1, NT, NX)
+        z2 = [a1[0] @ W2.T + b2] + [a1[s] @ W2.T for s in range(1, K)]
+        y2 = ln_fwd2(z2, g2, be2, eps, NT, NX)
+        q = [h[s] + y2[s] for s in range(K)]
+        tape["blocks"].append({"h": h, "z1": z1, "y1": y1, "a1": a1, "z2": z2, "q": q})
+        h = act_fwd(act, 0.0, q, NT, NX)
+    Wo, bo = sd["model.output_layer.weight"], sd["model.output_layer.bias"]
+    tape["h_last"] = h
+    u = [h[0] @ Wo.T + bo] + [h[s] @ Wo.T for s in range(1, K)]
+    return u, tape
+
+
+def resnet_jets_backward(spec, sd, tape, ubar, NT, NX, eps=1e-5):
+    K = 1 + NT + NX
+    nb = spec.num_blocks if spec.num_blocks is not None else spec.num_layers
+    act = spec.activation
+    g = {}
+    Wo = sd["model.output_layer.weight"]
+    h = tape["h_last"]
+    g["model.output_layer.weight"] = sum(ubar[s].T @ h[s] for s in range(K))
+    g["model.output_layer.bias"] = ubar[0].sum(0)
+    hb = [ubar[s] @ Wo for s in range(K)]
+    for b in range(nb - 1, -1, -1):
+        p = f"model.blocks.{b}.layers."
+        T = tape["blocks"][b]
+        W1, g1 = sd[p + "0.weight"], sd[p + "1.weight"]
+        W2, g2 = sd[p + "4.weight"], sd[p + "5.weight"]
+        qb = act_bwd(act, 0.0, T["q"], hb, NT, NX)
+        z2b, dg2, db2 = ln_bwd(T["z2"], qb, g2, eps, NT, NX)
+        g[p + "5.weight"], g[p + "5.bias"] = dg2, db2
+        g[p + "4.weight"] = sum(z2b[s].T @ T["a1"][s] for s in range(K))
+        g[p + "4.bias"] = z2b[0].sum(0)
+        a1b = [z2b[s] @ W2 for s in range(K)]
+        y1b = act_bwd(act, 0.0, T["y1"], a1b, NT, NX)
+        z1b, dg1, db1 = ln_bwd(T["z1"], y1b, g1, eps, NT, NX)
+        g[p + "1.weight"], g[p + "1.bias"] = dg1, db1
+        g[p + "0.weight"] = sum(z1b[s].T @ T["h"][s] for s in range(K))
+        g[p + "0.bias"] = z1b[0].sum(0)
+        hb = [z1b[s] @ W1 + qb[s] for s in range(K)]
+    z0b = act_bwd(act, 0.0, tape["z0"], hb, NT, NX)
+    a = tape["inp_streams"]
+    g["model.input_layer.weight"] = sum(z0b[s].T @ a[s] for s in range(K))
+    g["model.input_layer.bias"] = z0b[0].sum(0)
+    return g
+
+
+# ----------------------------------------------------------------------------
+# Attention network with a length-1 sequence (mirrors csrc/jet_kernel_attn.h)
+#   h0 = act(W_in (x,t) + b_in)
+#   layer l:  h <- LN_a(W_p (W_v h + b_v) + b_p + h)          (softmax over one key is 1: q/k are dead)
+#             h <- LN_f(h + W_2 gelu(W_1 h + b_1) + b_2)
+#   u = w_out . h + b_out
+# ----------------------------------------------------------------------------
+def _lin(a, W, b, K):
+    return [a[0] @ W.T + b] + [a[s] @ W.T for s in range(1, K)]
+
+
+def attention_jets_forward(spec, sd, inp, NT, NX, eps=1e-5):
+    K = 1 + NT + NX
+    a = input_streams(inp, NT, NX)
+    z0 = _lin(a, sd["model.input_proj.weight"], sd["model.input_proj.bias"], K)
+    h = act_fwd(spec.activation, 0.0, z0, NT, NX)
+    tape = {"inp_streams": a, "z0": z0, "layers": []}
+    for l in range(spec.num_layers):
+        pa, pf = f"model.layers.{l}.0.", f"model.layers.{l}.1."
+        v = _lin(h, sd[pa + "value.weight"], sd[pa + "value.bias"], K)
+        p = _lin(v, sd[pa + "proj.weight"], sd[pa + "proj.bias"], K)
+        za = [p[s] + h[s] for s in range(K)]
+        h1 = ln_fwd2(za, sd[pa + "layer_norm.weight"], sd[pa + "layer_norm.bias"], eps, NT, NX)
+        z1 = _lin(h1, sd[pf + "net.0.weight"], sd[pf + "net.0.bias"], K)
+        g1 = act_fwd("gelu", 0.0, z1, NT, NX)
+        f2 = _lin(g1, sd[pf + "net.3.weight"], sd[pf + "net.3.bias"], K)
+        zf = [h1[s] + f2[s] for s in range(K)]
+        h2 = ln_fwd2(zf, sd[pf + "layer_norm.weight"], sd[pf + "layer_norm.bias"], eps, NT, NX)
+        tape["layers"].append({"h": h, "v": v, "za": za, "h1": h1, "z1": z1, "g1": g1, "zf": zf})
+        h = h2
+    tape["h_last"] = h
+    u = _lin(h, sd["model.output_proj.weight"], sd["model.output_proj.bias"], K)
+    return u, tape
+
+
+def attention_jets_backward(spec, sd, tape, ubar, NT, NX, eps=1e-5):
+    K = 1 + NT + NX
+    g = {}
+
+    def lin_bwd(name, zb, a_in):
+        g[name + ".weight"] = sum(zb[s].T @ a_in[s] for s in range(K))
+        g[name + ".bias"] = zb[0].sum(0)
+        return [zb[s] @ sd[name + ".weight"] for s in range(K)]
+
+    hb = lin_bwd("model.output_proj", ubar, tape["h_last"])
+    for l in range(spec.num_layers - 1, -1, -1):
+        pa, pf = f"model.layers.{l}.0.", f"model.layers.{l}.1."
+        T = tape["layers"][l]
+        zfb, dg, db = ln_bwd(T["zf"], hb, sd[pf + "layer_norm.weight"], eps, NT, NX)
+        g[pf + "layer_norm.weight"], g[pf + "layer_norm.bias"] = dg, db
+        g1b = lin_bwd(pf + "net.3", zfb, T["g1"])
+        z1b = act_bwd("gelu", 0.0, T["z1"], g1b, NT, NX)
+        h1b = lin_bwd(pf + "net.0", z1b, T["h1"])
+        h1b = [h1b[s] + zfb[s] for s in range(K)]
+        zab, dg, db = ln_bwd(T["za"], h1b, sd[pa + "layer_norm.weight"], eps, NT, NX)
+        g[pa + "layer_norm.weight"], g[pa + "layer_norm.bias"] = dg, db
+        vb = lin_bwd(pa + "proj", zab, T["v"])
+        hb2 = lin_bwd(pa + "value", vb, T["h"])
+        hb = [hb2[s] + zab[s] for s in range(K)]
+        for dead in ("query", "key"):  # zero gradient: the attention weights are identically 1
+            g[pa + dead + ".weight"] = torch.zeros_like(sd[pa + dead + ".weight"])
+            g[pa + dead + ".bias"] = torch.zeros_like(sd[pa + dead + ".bias"])
+    z0b = act_bwd(spec.activation, 0.0, tape["z0"], hb, NT, NX)
+    a = tape["inp_streams"]
+    g["model.input_proj.weight"] = sum(z0b[s].T @ a[s] for s in range(K))
+    g["model.input_proj.bias"] = z0b[0].sum(0)
+    return g

@@ -86,6 +86,28 @@ def test_compute_derivatives_keys_and_values(tag, dev):
         pde.compute_derivatives(model, x, t, spatial_derivatives=[5])
 
 
+@pytest.mark.parametrize("tag", ["allen_cahn_resnet_2x32", "cahn_hilliard2d_attention_2x32"])
+def test_layernorm_architectures_through_the_api(tag, dev):
+    cfg, model, pde, (spec, ps, sd, a, m) = build(tag, dev)
+    x, t = torch.from_numpy(a["x"]).to(dev), torch.from_numpy(a["t"]).to(dev)
+    r = pde.compute_residual(model, x, t)
+    assert rel_l2(r.detach().cpu(), a["residual64"]) <= TOL
+    u = model(torch.cat([x, t], 1))
+    assert rel_l2(u.detach().cpu(), a["u64"]) <= TOL
+    if pde.dimension == 1:
+        loss = pde.compute_loss(model, x, t)["residual"]
+    else:
+        # pde_base.py:1102-1131 builds 1-column boundary points whatever the dimension, so the reference's base
+        # compute_loss raises on a 2-D problem; the mirror keeps that and the residual term is taken directly.
+        with pytest.raises((ValueError, RuntimeError)):
+            pde.compute_loss(model, x, t)
+        loss = pde._residual_loss(model, x, t)
+    loss.backward()
+    got = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten().cpu() for _, p in model.named_parameters()])
+    # attention: exact parity; resnet: within torch's fused-LayerNorm error of the reference
+    assert rel_l2(got, a["grad64"]) <= (TOL if spec.architecture == "attention" else 5e-4)
+
+
 def test_compute_loss_terms_match_oracle(dev):
     import oracle as O
 
@@ -97,6 +119,26 @@ def test_compute_loss_terms_match_oracle(dev):
     for k in ("residual", "boundary", "initial", "total"):
         assert abs(float(losses[k]) - float(want[k])) <= 2e-5 * abs(float(want[k])), k
     assert set(losses) >= {"residual", "boundary", "initial", "smoothness", "data", "total"}
+    losses["total"].backward()
+    names = [k for k in params if params[k].requires_grad]
+    gw = torch.autograd.grad(want["total"], [params[k] for k in names])
+    got = torch.cat([p.grad.flatten().cpu() for _, p in model.named_parameters()])
+    assert rel_l2(got, torch.cat([g.flatten() for g in gw])) <= 2e-5
+
+
+def test_heat_compute_loss_periodic_bc_matches_oracle(dev):
+    """HeatEquation's own compute_loss (heat_equation.py:375-623): periodic BC on u and du/dx — the boundary du/dx
+    the reference gets from autograd w.r.t. the boundary points is the x-stream of the jet kernel."""
+    import oracle as O
+
+    cfg, model, pde, (spec, ps, sd, a, m) = build("heat_fourier_4x128", dev)
+    x, t = torch.from_numpy(a["x"]).to(dev), torch.from_numpy(a["t"]).to(dev)
+    losses = pde.compute_loss(model, x, t)
+    params = {k: v.clone().requires_grad_(k != "model.fourier.B") for k, v in sd.items()}
+    want = O.compute_loss_terms_heat(ps, lambda z: O.network_forward(spec, params, z), torch.from_numpy(a["x"]),
+                                     torch.from_numpy(a["t"]))
+    for k in ("residual", "boundary", "initial", "total"):
+        assert abs(float(losses[k].detach()) - float(want[k].detach())) <= 2e-5 * abs(float(want[k].detach())), k
     losses["total"].backward()
     names = [k for k in params if params[k].requires_grad]
     gw = torch.autograd.grad(want["total"], [params[k] for k in names])

@@ -13,7 +13,7 @@ print(torch.cuda.get_device_name(0), torch.version.hip, flush=True)
 only = sys.argv[1:] 
 for tag in CASES:
     spec, pde, sd, a, m = load_case(tag)
-    if spec.architecture not in ("fourier", "feedforward", "siren"):
+    if spec.architecture not in ("fourier", "feedforward", "siren", "resnet", "attention"):
         continue
     if only and tag not in only:
         continue
@@ -39,6 +39,14 @@ for tag in CASES:
         by = {n: g for n, g in zip(names, grads) if g is not None}
         got = torch.cat([by[k].flatten().cpu() for k in m["param_names"]])
         msg.append(f"| bwd r {rel_l2(r2.cpu(), a['residual64']):.1e} grad {rel_l2(got, a['grad64']):.1e}")
+        if spec.architecture == "resnet":  # exact gradient (composite LayerNorm, fp64): torch's fused LN is inexact at 3rd order
+            sd64 = {k: v.double() for k, v in sd.items()}
+            x64, t64 = torch.from_numpy(a["x"]).double(), torch.from_numpy(a["t"]).double()
+            jj, tp = J.resnet_jets_forward(spec, sd64, torch.cat([x64, t64], 1), NT, NX)
+            rr, dr = J.pde_residual(pde.name, pde.parameters, jj, x64[:, 0:1], NT, NX, pde.dimension)
+            ge = J.resnet_jets_backward(spec, sd64, tp, [2.0 * rr / N * d for d in dr], NT, NX)
+            exact = torch.cat([ge[k].flatten() for k in m["param_names"]])
+            msg.append(f"grad-vs-exact {rel_l2(got, exact):.1e}")
         print(f"{tag:40s} " + " ".join(msg), flush=True)
         # per tensor
         off = 0
