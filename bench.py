@@ -84,11 +84,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device(f"cuda:{local}")
+    # PINN_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a ONE-GPU box (all ranks on cuda:0, gloo instead of
+    # RCCL, which refuses two ranks on one device).  Not a measurement mode.
+    rehearsal = os.environ.get("PINN_BENCH_REHEARSAL") == "1"
+    dev = torch.device("cuda:0" if rehearsal else f"cuda:{local}")
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from __graft_entry__ import _burgers
     from pinnrl_amd import engine as E
@@ -169,6 +175,8 @@ def main():
             },
             "residual_l2": math.sqrt(float(loss_sum) / n_global),
         }
+        if rehearsal:
+            out["config"]["rehearsal"] = "all ranks on cuda:0 over gloo - code-path check, not a measurement"
         if world == 1 and not args.no_cpu:
             cb, L_cpu, g_cpu = cpu_baseline(model, x_cpu, t_cpu, args.cpu_seconds)
             out["cpu_baseline"] = cb

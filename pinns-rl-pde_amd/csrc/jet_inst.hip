@@ -1,6 +1,8 @@
 // One translation unit per (time_order, space_order) stream set; the Makefile compiles this file
 // several times with -DPINN_NT=.. -DPINN_NX=.. so the instantiations build in parallel.
+#ifndef PINN_DEV_WIDE
 #include "jet_kernel_attn.h"
+#endif
 #include "jet_kernel_wide.h"
 
 #ifndef PINN_NT
@@ -11,14 +13,21 @@
 #define PINN_CAT(a, b, c) PINN_CAT2(a, b, c)
 
 namespace pinn {
+#ifdef PINN_DEV_WIDE /* make dev WIDE=1: only the wide kernel, for quick iteration on it */
+hipError_t PINN_CAT(launch_jet_, PINN_NT, PINN_NX)(const KernelArgs&, bool, int, int, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t PINN_CAT(launch_jetr_, PINN_NT, PINN_NX)(const KernelArgs&, bool, int, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t PINN_CAT(launch_jeta_, PINN_NT, PINN_NX)(const KernelArgs&, bool, int, hipStream_t) { return hipErrorInvalidValue; }
+#else
 // stream-serial kernel: any K, widths up to 256
 hipError_t PINN_CAT(launch_jet_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, int occ, hipStream_t stream) {
   return launch_jet<PINN_NT, PINN_NX>(a, bwd, grid, occ, stream);
 }
+#endif
 // wide kernel: all K streams LDS-resident, persistent dW accumulators (K * Hmax small enough)
 hipError_t PINN_CAT(launch_jetw_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
   return launch_jet_wide<PINN_NT, PINN_NX>(a, bwd, grid, stream);
 }
+#ifndef PINN_DEV_WIDE
 // ResNet kernel (LayerNorm jets; derivative orders <= 2)
 hipError_t PINN_CAT(launch_jetr_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
   return launch_jet_resnet<PINN_NT, PINN_NX>(a, bwd, grid, stream);
@@ -27,4 +36,5 @@ hipError_t PINN_CAT(launch_jetr_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bw
 hipError_t PINN_CAT(launch_jeta_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
   return launch_jet_attn<PINN_NT, PINN_NX>(a, bwd, grid, stream);
 }
+#endif
 }  // namespace pinn

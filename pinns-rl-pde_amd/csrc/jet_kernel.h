@@ -30,6 +30,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "jet_device.h"
 
 namespace pinn {
@@ -104,10 +108,26 @@ struct KernelArgs {
   unsigned long long* stamps;               // diagnostic builds (-DPINN_STAMPS) only: [grid][4 waves][kNumStamps] cycles
 };
 
+// Every kernel of this family may use the whole 160 KB LDS of a CU as dynamic shared memory.  The attribute is set
+// ONCE per (kernel, device) — not per launch: it is a driver call on the launch path, and it is not allowed while
+// the stream is being captured into a HIP graph.
+inline hipError_t allow_full_lds(const void* kern) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> guard(mu);
+  if (done.count({kern, dev})) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) done.insert({kern, dev});
+  return e;
+}
+
 // In-kernel phase timing for diagnostic builds; in normal builds these expand to nothing.
 constexpr int kNumStamps = 16;
 enum { ST_STAGE = 0, ST_ENCODE, ST_FWD_GEMM, ST_FWD_EW, ST_OUT, ST_EPI, ST_B0, ST_BWD_EW, ST_BWD_STREAM, ST_BWD_FLUSH,
-       ST_ENC_BWD, ST_TOTAL };
+       ST_ENC_BWD, ST_TOTAL, ST_BWD_DX, ST_BWD_PUT };
 #ifdef PINN_STAMPS
 #define PINN_STAMP_DECL unsigned long long st_acc[kNumStamps] = {}; unsigned long long st_prev = pinn_now(); const unsigned long long st_begin = st_prev;
 #define PINN_STAMP(idx) do { const unsigned long long st_now = pinn_now(); st_acc[idx] += st_now - st_prev; st_prev = st_now; } while (0)
@@ -125,8 +145,21 @@ __device__ __forceinline__ unsigned long long pinn_now() {
 
 __device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
-__device__ __forceinline__ long long tape_idx(int l, int jt, int ntile, int K, int s, int r, int tid) {
-  return ((((long long)(l * ntile + jt) * K + s) * 16 + r) * kThreads) + tid;
+// Tape layout: record (slot l, tile jt, stream s) is 16 registers x 256 threads, stored so that the four
+// consecutive accumulator registers 4q .. 4q+3 of a thread are one aligned 16-byte word ([q][tid][i]): the
+// reverse sweep moves it with global_load/store_dwordx4 (4x fewer VMEM instructions than dword accesses).
+// The slot / stream / group part of the address is wave-uniform (scalar base), the thread part a 32-bit byte
+// offset: global_load/store_dwordx4 v, v_off, s[base:base+1] — no per-access 64-bit address VGPR pairs.
+__device__ __forceinline__ long long tape_qbase(int l, int jt, int ntile, int K, int s, int q) {
+  return ((((long long)(l * ntile + jt) * K + s) * 4 + q) * kThreads) * 4;
+}
+__device__ __forceinline__ f32x4 tape_ld4(const float* tape, int l, int jt, int ntile, int K, int s, int q, int tid) {
+  const char* base = reinterpret_cast<const char*>(tape + tape_qbase(l, jt, ntile, K, s, q));
+  return *reinterpret_cast<const f32x4*>(base + static_cast<unsigned>(tid) * 16u);
+}
+__device__ __forceinline__ void tape_st4(float* tape, int l, int jt, int ntile, int K, int s, int q, int tid, f32x4 v) {
+  char* base = reinterpret_cast<char*>(tape + tape_qbase(l, jt, ntile, K, s, q));
+  *reinterpret_cast<f32x4*>(base + static_cast<unsigned>(tid) * 16u) = v;
 }
 
 struct Lane {
@@ -483,18 +516,25 @@ template <int ACT, int NT, int NX, int NTILE, bool TAPE>
 __device__ __forceinline__ void ew_forward(f32x16 (&v)[1 + NT + NX], float w, float* tape, int l, int jt, int tid) {
   constexpr int K = 1 + NT + NX;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float z[K], y[K];
+  for (int q = 0; q < 4; ++q) {
+    f32x4 rec[K];
 #pragma unroll
-    for (int s = 0; s < K; ++s) z[s] = v[s][r];
-    act_fwd<ACT, NT, NX>(w, z, y);
-    if constexpr (TAPE) {
-      tape[tape_idx(l, jt, NTILE, K, 0, r, tid)] = ActTape<ACT>::value_is_output ? y[0] : z[0];
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * q + i;
+      float z[K], y[K];
 #pragma unroll
-      for (int s = 1; s < K; ++s) tape[tape_idx(l, jt, NTILE, K, s, r, tid)] = z[s];
+      for (int s = 0; s < K; ++s) z[s] = v[s][r];
+      act_fwd<ACT, NT, NX>(w, z, y);
+      rec[0][i] = ActTape<ACT>::value_is_output ? y[0] : z[0];
+#pragma unroll
+      for (int s = 1; s < K; ++s) rec[s][i] = z[s];
+#pragma unroll
+      for (int s = 0; s < K; ++s) v[s][r] = y[s];
     }
+    if constexpr (TAPE) {
 #pragma unroll
-    for (int s = 0; s < K; ++s) v[s][r] = y[s];
+      for (int s = 0; s < K; ++s) tape_st4(tape, l, jt, NTILE, K, s, q, tid, rec[s]);
+    }
   }
 }
 
@@ -504,16 +544,23 @@ __device__ __forceinline__ void ew_backward(f32x16 (&ab)[1 + NT + NX], float w, 
                                             int tid) {
   constexpr int K = 1 + NT + NX;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float z[K], abv[K], zb[K];
+  for (int q = 0; q < 4; ++q) {
+    f32x4 rec[K];
 #pragma unroll
-    for (int s = 0; s < K; ++s) {
-      z[s] = tape[tape_idx(l, jt, NTILE, K, s, r, tid)];
-      abv[s] = ab[s][r];
+    for (int s = 0; s < K; ++s) rec[s] = tape_ld4(tape, l, jt, NTILE, K, s, q, tid);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * q + i;
+      float z[K], abv[K], zb[K];
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        z[s] = rec[s][i];
+        abv[s] = ab[s][r];
+      }
+      act_bwd_tape<ACT, NT, NX>(w, z, abv, zb);
+#pragma unroll
+      for (int s = 0; s < K; ++s) ab[s][r] = zb[s];
     }
-    act_bwd_tape<ACT, NT, NX>(w, z, abv, zb);
-#pragma unroll
-    for (int s = 0; s < K; ++s) ab[s][r] = zb[s];
   }
 }
 
@@ -522,13 +569,19 @@ template <int ACT, int NT, int NX, int NTILE>
 __device__ __forceinline__ void ew_replay(f32x16 (&a)[1 + NT + NX], float w, const float* tape, int l, int jt, int tid) {
   constexpr int K = 1 + NT + NX;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float z[K], y[K];
+  for (int q = 0; q < 4; ++q) {
+    f32x4 rec[K];
 #pragma unroll
-    for (int s = 0; s < K; ++s) z[s] = tape[tape_idx(l, jt, NTILE, K, s, r, tid)];
-    act_fwd_tape<ACT, NT, NX>(w, z, y);
+    for (int s = 0; s < K; ++s) rec[s] = tape_ld4(tape, l, jt, NTILE, K, s, q, tid);
 #pragma unroll
-    for (int s = 0; s < K; ++s) a[s][r] = y[s];
+    for (int i = 0; i < 4; ++i) {
+      float z[K], y[K];
+#pragma unroll
+      for (int s = 0; s < K; ++s) z[s] = rec[s][i];
+      act_fwd_tape<ACT, NT, NX>(w, z, y);
+#pragma unroll
+      for (int s = 0; s < K; ++s) a[s][4 * q + i] = y[s];
+    }
   }
 }
 
@@ -556,14 +609,21 @@ __device__ __forceinline__ void tape_put(const f32x16 (&v)[K], float* tape, int 
 #pragma unroll
   for (int s = 0; s < K; ++s)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tape[tape_idx(slot, jt, NTILE, K, s, r, tid)] = v[s][r];
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 w4 = {v[s][4 * q], v[s][4 * q + 1], v[s][4 * q + 2], v[s][4 * q + 3]};
+      tape_st4(tape, slot, jt, NTILE, K, s, q, tid, w4);
+    }
 }
 template <int K, int NTILE>
 __device__ __forceinline__ void tape_get(f32x16 (&v)[K], const float* tape, int slot, int jt, int tid) {
 #pragma unroll
   for (int s = 0; s < K; ++s)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[s][r] = tape[tape_idx(slot, jt, NTILE, K, s, r, tid)];
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 w4 = tape_ld4(tape, slot, jt, NTILE, K, s, q, tid);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[s][4 * q + i] = w4[i];
+    }
 }
 
 // Deferred weight-gradient flush (NTILE == 1): the 64 atomics of a layer's dW tile row are issued 16 at a time
@@ -576,13 +636,14 @@ struct PendingDW {
   f32x16 acc[NKT];
   float* base;  // dW + (32 ft + 4 lh) * in_dim + ln   (row offset of register r added at issue)
   int in_dim;   // row stride of dW
+  int ncol;     // valid columns minus this lane's column offset: k-tile kt is written iff kt * 32 < ncol
   int na;       // active k-tiles
   bool live;
 };
 
 template <int NKT>
 __device__ __forceinline__ void drain_tile(PendingDW<NKT>& P, int kt_const, const f32x16& vals) {
-  if (P.live && kt_const < P.na) {
+  if (P.live && kt_const < P.na && kt_const * 32 < P.ncol) {  // in_dim may end inside a k-tile (24 Fourier features)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       atomicAdd(P.base + (long long)((r & 3) + 8 * (r >> 2)) * P.in_dim + kt_const * 32, vals[r]);
@@ -929,6 +990,7 @@ __global__ __launch_bounds__(kThreads, OCC) void jet_kernel(const KernelArgs a) 
             for (int kt = 0; kt < NKT; ++kt) pend.acc[kt] = dacc[0][kt];
             pend.base = Ly.dW + (long long)(L.wave * 32 + 4 * L.lh) * Ly.ld + L.ln;
             pend.in_dim = Ly.ld;
+            pend.ncol = Ly.in_dim - L.ln;
             pend.na = (Ly.in_dim + 31) >> 5;
             pend.live = true;
             // Measured: draining behind later MFMA work does not help — atomics share the in-order vmcnt queue
@@ -946,8 +1008,9 @@ __global__ __launch_bounds__(kThreads, OCC) void jet_kernel(const KernelArgs a) 
                 if (kt * 32 < Ly.in_dim) {
 #pragma unroll
                   for (int r = 0; r < 16; ++r)
-                    atomicAdd(Ly.dW + (long long)(ft * 32 + acc_row(r, L.lh)) * Ly.ld + kt * 32 + L.ln,
-                              dacc[jt][kt][r]);
+                    if (kt * 32 + L.ln < Ly.in_dim)  // in_dim may end inside a k-tile (e.g. 24 Fourier features)
+                      atomicAdd(Ly.dW + (long long)(ft * 32 + acc_row(r, L.lh)) * Ly.ld + kt * 32 + L.ln,
+                                dacc[jt][kt][r]);
                 }
               }
             }
@@ -1044,8 +1107,7 @@ hipError_t launch_jet(const KernelArgs& a, bool bwd, int grid, int occ, hipStrea
 #define PINN_LAUNCH1(ACT_, NTILE_, BWD_, OCC_)                                                               \
   do {                                                                                                       \
     auto kern = jet_kernel<ACT_, NT, NX, NTILE_, BWD_, OCC_>;                                                          \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            (int)lds);                                                                       \
+    e = allow_full_lds(reinterpret_cast<const void*>(kern));                                                 \
     if (e != hipSuccess) return e;                                                                           \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, a);                                    \
   } while (0)

@@ -368,8 +368,7 @@ hipError_t launch_jet_attn(const KernelArgs& a, bool bwd, int grid, hipStream_t 
 #define PINN_ALAUNCH1(ACT_, NTILE_, BWD_)                                                                    \
   do {                                                                                                       \
     auto kern = jet_kernel_attn<ACT_, NT, NX, NTILE_, BWD_>;                                                 \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            (int)lds);                                                                       \
+    e = allow_full_lds(reinterpret_cast<const void*>(kern));                                                 \
     if (e != hipSuccess) return e;                                                                           \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, a);                                    \
   } while (0)

@@ -299,7 +299,7 @@ static int occupancy_for(const NetDev& n, size_t lds, bool bwd) {
 // Kernel variant: "wide" (all K streams LDS-resident, persistent dW accumulators) whenever it fits, else the
 // stream-serial kernel.  PINN_KERNEL=stream|wide overrides for experiments and tests.
 static bool use_wide(const NetDev& n, int K, bool bwd) {
-  const bool fits = jet_wide_fits(K, n.hmax, bwd);
+  const bool fits = jet_wide_fits(K, n.hmax, bwd, n.n_layers);
   if (const char* e = getenv("PINN_KERNEL")) {
     if (!strcmp(e, "stream")) return false;
   }
@@ -312,7 +312,7 @@ static int grid_for(const NetDev& n, int K, long long N, bool bwd, size_t* lds_o
   const bool wide = !resnet && use_wide(n, K, bwd);
   if (wide_out) *wide_out = wide;
   const size_t lds = resnet ? jet_resnet_lds_bytes(K, n.hmax, bwd)
-                            : (wide ? jet_wide_lds_bytes(K, n.hmax, bwd) : jet_lds_bytes(K, n.hmax, bwd));
+                            : (wide ? jet_wide_lds_bytes(K, jet_wide_hmax(n.hmax), bwd, n.n_layers) : jet_lds_bytes(K, n.hmax, bwd));
   if (lds_out) *lds_out = lds;
   if (lds > kLdsLimit) return 0;
   const long long ntiles = (N + kT - 1) / kT;

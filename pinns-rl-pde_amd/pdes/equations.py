@@ -153,7 +153,7 @@ class HeatEquation(PDEBase):
         n_early = max(nbp // 4, 1)
         tb = torch.cat([torch.linspace(0, t_early, n_early, device=dev),
                         torch.linspace(t_early, t_max, nbp - n_early, device=dev)]).reshape(-1, 1)
-        boundary_loss = torch.tensor(0.0, device=dev)
+        boundary_loss = torch.zeros((), device=dev)
         if self.dimension == 1:
             x_lo, x_hi = self.config.domain[0]
             jl = model.jets(torch.full((nbp, 1), x_lo, device=dev), tb, 1, 1)  # streams: u, u_t, u_x
@@ -195,7 +195,7 @@ class HeatEquation(PDEBase):
                 target = target * torch.sin(k * torch.pi * xi[:, d : d + 1])
         initial_loss = self._apply_loss_fn(ui - target)
         lw = self._loss_weights()
-        smoothness_loss = torch.tensor(0.0, device=dev)
+        smoothness_loss = torch.zeros((), device=dev)
         if lw and lw.get("smoothness", 0.0) > 0:
             smoothness_loss = self._compute_smoothness_loss(model, x, t)
         return self._compose_losses(residual_loss, boundary_loss, initial_loss, smoothness_loss,
@@ -205,7 +205,7 @@ class HeatEquation(PDEBase):
         eps = 1e-4
         x, t = x.detach(), t.detach()
         uc = model(torch.cat([x, t], dim=1))
-        out = torch.tensor(0.0, device=self.device)
+        out = torch.zeros((), device=self.device)
         for d in range(self.dimension):
             xp, xm = x.clone(), x.clone()
             xp[:, d : d + 1] = torch.clamp(x[:, d : d + 1] + eps, self.domain[d][0], self.domain[d][1])

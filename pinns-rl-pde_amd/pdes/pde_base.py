@@ -195,7 +195,7 @@ class PDEBase:
     def _compute_data_loss(self, model) -> torch.Tensor:  # pde_base.py:281-291
         obs = getattr(self, "observation_data", None)
         if not obs:
-            return torch.tensor(0.0, device=self.device)
+            return torch.zeros((), device=self.device)
         return self._apply_loss_fn(model(torch.cat([obs["x"], obs["t"]], dim=1)) - obs["u"])
 
     def _load_observation_data(self, obs_cfg):  # pde_base.py:353-415 (the network-backed "well" source is out of scope)
@@ -509,6 +509,28 @@ class PDEBase:
         terms enter `total` with weight 1/world, so that a SUM all-reduce of the gradients is exact."""
         dev = self.device
         residual_loss = self._residual_loss(model, x, t, n_total)
+        inp_b, xb, tb, inp_i, xi, ti = self._boundary_and_initial_points()
+        boundary_loss = torch.zeros((), device=dev)
+        for bc_func in self.boundary_conditions.values():
+            boundary_loss = boundary_loss + self._apply_loss_fn(model(inp_b) - bc_func(xb, tb))
+        ui = model(inp_i)
+        if "initial" in self.boundary_conditions:
+            target = self.boundary_conditions["initial"](xi, ti)
+        else:
+            target = self._create_boundary_condition("initial", self.config.initial_condition)(xi, ti)
+        initial_loss = self._apply_loss_fn(ui - target)
+        data_loss = self._compute_data_loss(model)
+        smoothness_loss = torch.zeros((), device=dev)
+        return self._compose_losses(residual_loss, boundary_loss, initial_loss, smoothness_loss, data_loss, aux_scale)
+
+    def _boundary_and_initial_points(self):
+        """The fixed boundary (2*dim values x 100 times) and initial (100 x, t = 0) evaluation points of
+        pde_base.py:1101-1131, 1135-1141.  They depend only on the domain, so they are built once per device and
+        reused: no host-to-device copy inside the step (which also keeps the step capturable in a HIP graph)."""
+        dev = torch.device(self.device)
+        cache = getattr(self, "_bc_ic_points", None)
+        if cache is not None and cache[0] == dev:
+            return cache[1]
         if self.dimension == 1:
             xb = torch.tensor([self.domain[0][0], self.domain[0][1]], dtype=torch.float32, device=dev).reshape(-1, 1)
         else:
@@ -519,21 +541,12 @@ class PDEBase:
         tb = torch.linspace(self.time_domain[0], self.time_domain[1], 100, device=dev).reshape(-1, 1)
         xb = xb.repeat_interleave(len(tb), dim=0)
         tb = tb.repeat(len(xb) // len(tb), 1)
-        boundary_loss = torch.tensor(0.0, device=dev)
         inp_b = torch.cat([xb, tb], dim=1)
-        for bc_func in self.boundary_conditions.values():
-            boundary_loss = boundary_loss + self._apply_loss_fn(model(inp_b) - bc_func(xb, tb))
         xi = torch.linspace(self.domain[0][0], self.domain[0][1], 100, device=dev).reshape(-1, 1)
         ti = torch.zeros_like(xi)
-        ui = model(torch.cat([xi, ti], dim=1))
-        if "initial" in self.boundary_conditions:
-            target = self.boundary_conditions["initial"](xi, ti)
-        else:
-            target = self._create_boundary_condition("initial", self.config.initial_condition)(xi, ti)
-        initial_loss = self._apply_loss_fn(ui - target)
-        data_loss = self._compute_data_loss(model)
-        smoothness_loss = torch.tensor(0.0, device=dev)
-        return self._compose_losses(residual_loss, boundary_loss, initial_loss, smoothness_loss, data_loss, aux_scale)
+        inp_i = torch.cat([xi, ti], dim=1)
+        self._bc_ic_points = (dev, (inp_b, xb, tb, inp_i, xi, ti))
+        return self._bc_ic_points[1]
 
     def _compose_losses(self, residual_loss, boundary_loss, initial_loss, smoothness_loss, data_loss, aux_scale=1.0):
         """The weighting / mode gating tail shared by every `compute_loss` (pde_base.py:1168-1235, heat_equation.py:543-623)."""

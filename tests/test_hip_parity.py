@@ -194,6 +194,36 @@ def test_partial_tile_and_multi_tile_consistency(dev):
     assert abs(float(s_all) / xb.shape[0] - float(L_o)) <= 1e-5 * float(L_o)
 
 
+@pytest.mark.parametrize("kernel", ["default", "stream"])
+def test_fourier_feature_count_not_a_multiple_of_32(dev, kernel, monkeypatch):
+    """mapping_size = 12 -> 24 Fourier features: the first MFMA layer's input width ends inside a 32-wide k-tile
+    (pinned against the oracle on the fly; poisons LDS first so that never-written rows cannot pass as zeros)."""
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import engine as E
+    import oracle as O
+
+    if kernel == "stream":
+        monkeypatch.setenv("PINN_KERNEL", "stream")
+    spec = O.ArchSpec("fourier", hidden_dim=64, num_layers=3, mapping_size=12, scale=2.0)
+    pde = O.PdeSpec(name="burgers", parameters={"nu": 0.02})
+    sd = O.init_state_dict(spec, seed=5)
+    torch.manual_seed(6)
+    x, t = O.sample_uniform(pde, 500)
+    r_o, L_o, g_o = O.residual_loss_and_grad(pde, spec, sd, x, t)
+    prog, names = program_from_spec(spec, sd, dev)
+    pd = pde_desc_from_spec(pde)
+    torch.full((1 << 22,), float("nan"), device=dev).sum()  # a NaN-laden kernel's registers / LDS precede ours
+    flat = E.new_flat_grad(prog, dev)
+    r, s = E.residual_loss_grad(prog, pd, x.to(dev), t.to(dev), 1.0 / x.shape[0], flat, want_residual=True)
+    assert rel_l2(r.cpu(), r_o) <= TOL
+    assert abs(float(s) / x.shape[0] - float(L_o)) <= TOL * abs(float(L_o))
+    by_name = {n: g for n, g in zip(names, E.split_flat_grad(prog, flat)) if g is not None}
+    keys = [k for k in g_o if k in by_name]
+    got = torch.cat([by_name[k].flatten().cpu() for k in keys])
+    want = torch.cat([g_o[k].flatten() for k in keys])
+    assert torch.isfinite(got).all() and rel_l2(got, want) <= TOL
+
+
 def test_cpu_tensors_are_refused():
     from pinnrl_amd import engine as E
     from hip_helpers import program_from_spec

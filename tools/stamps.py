@@ -9,7 +9,7 @@ from __graft_entry__ import _burgers
 from pinnrl_amd import engine as E, _lib
 import oracle as O
 
-NAMES = ["stage", "encode", "fwd_gemm", "fwd_ew", "out", "epi", "b0", "bwd_ew", "bwd_stream", "bwd_flush", "enc_bwd", "TOTAL"]
+NAMES = ["stage", "encode", "fwd_gemm", "fwd_ew", "out", "epi", "b0", "bwd_ew", "bwd_stream", "bwd_flush", "enc_bwd", "TOTAL", "bwd_dx", "bwd_wait"]
 dev = torch.device("cuda:0")
 cfg, model, pde = _burgers(dev, hidden=128, layers=4, mapping=32, scale=10.0)
 torch.manual_seed(1)
@@ -34,6 +34,8 @@ live = st[:, :, 11].sum(1) > 0
 st = st[live]
 tot = st[:, :, 11]
 print(f"N={x.shape[0]} kernel {s0.elapsed_time(s1):.3f} ms; workgroups with work {int(live.sum())}; wave lifetime median {tot.median():.0f} cycles")
-for i, nm in enumerate(NAMES[:-1]):
+for i, nm in enumerate(NAMES):
+    if nm == "TOTAL":
+        continue
     v = st[:, :, i]
     print(f"  {nm:11s} median {v.median():10.0f}  share {100 * v.sum() / tot.sum():5.1f}%   (wave0 {st[:, 0, i].median():9.0f}  wave3 {st[:, 3, i].median():9.0f})")
