@@ -1,9 +1,13 @@
 // One translation unit per (time_order, space_order) stream set; the Makefile compiles this file
 // several times with -DPINN_NT=.. -DPINN_NX=.. so the instantiations build in parallel.
-#ifndef PINN_DEV_WIDE
+#if defined(PINN_DEV_STREAM)
+#include "jet_kernel.h"
+#elif !defined(PINN_DEV_WIDE)
 #include "jet_kernel_attn.h"
 #endif
+#ifndef PINN_DEV_STREAM
 #include "jet_kernel_wide.h"
+#endif
 
 #ifndef PINN_NT
 #error "compile with -DPINN_NT=<0..2> -DPINN_NX=<0..4>"
@@ -23,11 +27,17 @@ hipError_t PINN_CAT(launch_jet_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd
   return launch_jet<PINN_NT, PINN_NX>(a, bwd, grid, occ, stream);
 }
 #endif
+#ifdef PINN_DEV_STREAM /* make dev STREAM=1: only the stream-serial kernel */
+hipError_t PINN_CAT(launch_jetw_, PINN_NT, PINN_NX)(const KernelArgs&, bool, int, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t PINN_CAT(launch_jetr_, PINN_NT, PINN_NX)(const KernelArgs&, bool, int, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t PINN_CAT(launch_jeta_, PINN_NT, PINN_NX)(const KernelArgs&, bool, int, hipStream_t) { return hipErrorInvalidValue; }
+#else
 // wide kernel: all K streams LDS-resident, persistent dW accumulators (K * Hmax small enough)
 hipError_t PINN_CAT(launch_jetw_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
   return launch_jet_wide<PINN_NT, PINN_NX>(a, bwd, grid, stream);
 }
-#ifndef PINN_DEV_WIDE
+#endif
+#if !defined(PINN_DEV_WIDE) && !defined(PINN_DEV_STREAM)
 // ResNet kernel (LayerNorm jets; derivative orders <= 2)
 hipError_t PINN_CAT(launch_jetr_, PINN_NT, PINN_NX)(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
   return launch_jet_resnet<PINN_NT, PINN_NX>(a, bwd, grid, stream);

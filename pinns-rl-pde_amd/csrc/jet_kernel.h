@@ -332,21 +332,23 @@ __device__ __forceinline__ void load_wcols(WFrag& wf, const LayerDev& Ly, int kt
 template <int NG>
 __device__ __forceinline__ void gemm_frag_n(f32x16& acc, const WFrag& wf, const float* S, const Lane& L) {
   const float* col = S + (4 * L.lh) * kTP + L.ln;
-  constexpr int H0 = NG < 8 ? NG : 8;  // groups per half
+  // B operands run two k-groups (8 ds_read_b32) ahead of the 4 MFMAs that consume them; sched_barrier pins that
+  // order (left alone, the scheduler sinks each read to just before its MFMA and every MFMA waits out the LDS latency)
+  float b[3][4];
 #pragma unroll
-  for (int g0 = 0; g0 < NG; g0 += H0) {
-    float b[H0 * 4];
+  for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int g = 0; g < H0; ++g)
+    for (int i = 0; i < 4; ++i) b[g][i] = (g < NG) ? col[(8 * g + i) * kTP] : 0.0f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) b[4 * g + i] = (g0 + g < NG) ? col[(8 * (g0 + g) + i) * kTP] : 0.0f;
+  for (int g = 0; g < NG; ++g) {
+    if (g + 2 < NG) {
 #pragma unroll
-    for (int g = 0; g < H0; ++g) {
-      if (g0 + g < NG) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.g[g0 + g][i], b[4 * g + i], acc, 0, 0, 0);
-      }
+      for (int i = 0; i < 4; ++i) b[(g + 2) % 3][i] = col[(8 * (g + 2) + i) * kTP];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.g[g][i], b[g % 3][i], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -375,20 +377,31 @@ template <int NKT, int NA>  // NA = active k-tiles (in_dim / 32), compile-time s
 __device__ __forceinline__ void gemm_outer_n(f32x16 (&dacc)[NKT], int ft, const float* Z, const float* A, const Lane& L) {
   const float* zrow = Z + (ft * 32 + L.ln) * kTP + 4 * L.lh;
   const float* arow = A + L.ln * kTP + 4 * L.lh;
-  f32x4 zv[4], av[4][NA];
+  // operands of point group g+1 are requested before the 4 NA MFMAs of group g (pinned, see gemm_frag_n)
+  f32x4 zc, zn, ac[NA], an[NA];
+  zc = *reinterpret_cast<const f32x4*>(zrow);
+#pragma unroll
+  for (int kt = 0; kt < NA; ++kt) ac[kt] = *reinterpret_cast<const f32x4*>(arow + kt * 32 * kTP);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    zv[g] = *reinterpret_cast<const f32x4*>(zrow + 8 * g);
+    if (g + 1 < 4) {
+      zn = *reinterpret_cast<const f32x4*>(zrow + 8 * (g + 1));
 #pragma unroll
-    for (int kt = 0; kt < NA; ++kt) av[g][kt] = *reinterpret_cast<const f32x4*>(arow + kt * 32 * kTP + 8 * g);
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
+      for (int kt = 0; kt < NA; ++kt) an[kt] = *reinterpret_cast<const f32x4*>(arow + kt * 32 * kTP + 8 * (g + 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int kt = 0; kt < NA; ++kt)
-        dacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zv[g][i], av[g][kt][i], dacc[kt], 0, 0, 0);
+        dacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zc[i], ac[kt][i], dacc[kt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < 4) {
+      zc = zn;
+#pragma unroll
+      for (int kt = 0; kt < NA; ++kt) ac[kt] = an[kt];
+    }
+  }
 }
 
 template <int NKT>
@@ -1101,6 +1114,7 @@ inline long long jet_tape_floats_per_wg(int K, int n_layers, int ntile) {
 template <int NT, int NX>
 hipError_t launch_jet(const KernelArgs& a, bool bwd, int grid, int occ, hipStream_t stream) {
   constexpr int K = 1 + NT + NX;
+  (void)occ;  // the launch is sized by the caller; the register budget follows from (NTILE, BWD) below
   const int ntile = a.net.hmax > 128 ? 2 : 1;
   const size_t lds = jet_lds_bytes(K, a.net.hmax, bwd);
   hipError_t e = hipSuccess;
@@ -1111,9 +1125,17 @@ hipError_t launch_jet(const KernelArgs& a, bool bwd, int grid, int occ, hipStrea
     if (e != hipSuccess) return e;                                                                           \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, a);                                    \
   } while (0)
-#ifdef PINN_DEV /* fast-compiling developer build: tanh, width <= 128 only */
+#ifdef PINN_DEV /* fast-compiling developer build: ONE activation (default tanh) and ONE tile count (default 1) */
+#ifndef PINN_DEV_ACT
+#define PINN_DEV_ACT PINN_ACT_TANH
+#endif
+#ifndef PINN_DEV_NTILE
+#define PINN_DEV_NTILE 1
+#endif
 #define PINN_LAUNCH(NTILE_, BWD_, OCC_)                                                        \
-  if (act == PINN_ACT_TANH && NTILE_ == 1) PINN_LAUNCH1(PINN_ACT_TANH, 1, BWD_, OCC_); else return hipErrorInvalidValue;
+  if constexpr (NTILE_ == PINN_DEV_NTILE) {                                                    \
+    if (act == PINN_DEV_ACT) PINN_LAUNCH1(PINN_DEV_ACT, NTILE_, BWD_, OCC_); else return hipErrorInvalidValue; \
+  } else return hipErrorInvalidValue;
 #else
 #define PINN_LAUNCH(NTILE_, BWD_, OCC_)                                                        \
   switch (act) {                                                                               \
@@ -1127,7 +1149,7 @@ hipError_t launch_jet(const KernelArgs& a, bool bwd, int grid, int occ, hipStrea
   // every hidden layer of the supported architectures shares one activation (ENC_LINEAR's included)
   const int act = a.net.n_layers > 0 ? a.net.layer[0].act : a.net.enc_act;
   if (ntile == 1) {
-    if (bwd) { if (occ >= 2) PINN_LAUNCH(1, true, 2) else PINN_LAUNCH(1, true, 1) }
+    if (bwd) PINN_LAUNCH(1, true, 1)  // one workgroup per CU: the 256-register budget of two spills ~2000 VGPRs
     else PINN_LAUNCH(1, false, 2)
   } else {
     if (bwd) PINN_LAUNCH(2, true, 1) else PINN_LAUNCH(2, false, 1)

@@ -235,6 +235,50 @@ class PDETrainer:
         self.optimizer.step()
         return losses
 
+    # ---------------------------------------------------------------- graph-captured step
+    def make_graphed_step(self, batch_size: int, warmup: int = 3):
+        """Capture ONE whole training step — fresh device-side sample, compute_loss, backward, clip_grad_norm_, Adam —
+        in a HIP graph and return `(replay, losses)`: `replay()` runs a step, `losses` is the dict of STATIC loss
+        tensors it refreshes.  Same arithmetic as `train_step` on `_sample(batch_size)`; what it removes is the
+        per-step host work (~60 launch-bound kernels and the Python between them).  Requirements of graph capture:
+        Adam (made capturable: its step counter moves to the device), no adaptive loss weights, no RL/RAR sampling
+        (their control flow is host-side), gradients kept allocated (`zero_grad(set_to_none=False)`), one process,
+        and no autograd graph of an earlier eager step still referenced by the caller (drop old loss tensors first:
+        torch's capture of a backward that meets a stale AccumulateGrad node crashes on this ROCm build)."""
+        if self._is_lbfgs or self.use_adaptive_weights or self.process_group is not None or self.rl_agent is not None:
+            raise NotImplementedError("graph capture covers the single-process Adam step without adaptive loss weights "
+                                      "or RL-driven sampling")
+        if getattr(self.config.training, "collocation_distribution", "uniform") not in ("uniform", "stratified"):
+            raise NotImplementedError("graph capture needs a host-independent sampler (uniform / stratified)")
+        for g in self.optimizer.param_groups:
+            g["capturable"] = True
+        for st in self.optimizer.state.values():  # steps taken eagerly so far: counters move to the device
+            if "step" in st and not st["step"].is_cuda:
+                st["step"] = st["step"].to(self.device)
+        gc = self.config.training.gradient_clipping
+
+        def step():
+            x, t = self._sample(batch_size)
+            self.optimizer.zero_grad(set_to_none=False)
+            losses = self._losses(x, t)
+            losses["total"].backward()
+            if gc > 0:
+                nn.utils.clip_grad_norm_(self.model.parameters(), gc)
+            self.optimizer.step()
+            return losses
+
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):  # allocates gradients / optimizer state before capture
+                step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            losses = step()
+        self._step_graph = graph  # keeps the captured allocations alive
+        return graph.replay, {k: v.detach() for k, v in losses.items()}
+
     # ---------------------------------------------------------------- the loop (trainer.py:391-964)
     def train(self, num_epochs: int, batch_size: int, num_points: int, experiment_dir: str = None):
         self.model.train()

@@ -224,6 +224,27 @@ def test_fourier_feature_count_not_a_multiple_of_32(dev, kernel, monkeypatch):
     assert torch.isfinite(got).all() and rel_l2(got, want) <= TOL
 
 
+def test_empty_and_single_point_inputs(dev):
+    """N = 0 launches nothing and returns empty / zero results; N = 1 is one ragged tile."""
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import engine as E
+
+    spec, pde, sd, a, m = load_case("burgers_fourier_3x32")
+    prog, names = program_from_spec(spec, sd, dev)
+    pd = pde_desc_from_spec(pde)
+    x, t = torch.from_numpy(a["x"]).to(dev), torch.from_numpy(a["t"]).to(dev)
+    x0, t0 = x[:0], t[:0]
+    assert E.jets_forward(prog, x0, t0, 1, 2).shape == (4, 0)
+    r, s = E.residual_forward(prog, pd, x0, t0)
+    assert r.shape == (0, 1) and float(s) == 0.0
+    flat = E.new_flat_grad(prog, dev)
+    r, s = E.residual_loss_grad(prog, pd, x0, t0, 1.0, flat, want_residual=True)
+    assert r.shape == (0, 1) and float(s) == 0.0 and float(flat.abs().max()) == 0.0
+    r1, s1 = E.residual_forward(prog, pd, x[:1], t[:1])
+    assert abs(float(r1) - float(a["residual64"][0])) <= 1e-5 * (1 + abs(float(a["residual64"][0])))
+    assert abs(float(s1) - float(r1) ** 2) <= 1e-5 * float(r1) ** 2 + 1e-12
+
+
 def test_cpu_tensors_are_refused():
     from pinnrl_amd import engine as E
     from hip_helpers import program_from_spec

@@ -1,13 +1,11 @@
 """Full training step (SURVEY §8(d) "secondary: full-step pts/s", §8(f) rank 1) on ONE GPU, for context.
 
-    python tools/bench_step.py [--points 50000] [--steps 50]
+    python tools/bench_step.py [--points 50000] [--steps 50] [--graph]
 
 One step = fresh collocation sample -> compute_loss (fused residual launch + boundary + initial terms) -> backward ->
 clip_grad_norm_ -> Adam, i.e. `PDETrainer.train_step` as the reference's loop runs it (trainer.py:546-698).
-Every launch of the step except the fused residual is a small launch-bound kernel; capturing the step in a HIP graph
-is the obvious next move (the step issues no host-to-device copy and no driver call any more), but
-torch.cuda.graph capture of the custom-Function backward crashes on this torch 2.10 / ROCm 7 build, so it is not
-offered here.
+Every launch of the step except the fused residual is a small launch-bound kernel; with --graph the whole step is
+captured once in a HIP graph (`PDETrainer.make_graphed_step`) and replayed.
 """
 import argparse
 import os
@@ -27,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--graph", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg, model, pde = _burgers(dev, hidden=128, layers=4, mapping=32, scale=10.0)
@@ -37,11 +36,14 @@ def main():
         x, t = pde.generate_collocation_points(args.points, strategy="uniform")
         return trainer.train_step(x, t)
 
-    for _ in range(5):
-        losses = step()
-    torch.cuda.synchronize()
     n = int(pde.generate_collocation_points(args.points)[0].shape[0])
-    run = step
+    if args.graph:  # capture first: no autograd graph of an earlier eager step may still be alive at capture time
+        run, losses = trainer.make_graphed_step(args.points)
+    else:
+        run = step
+        for _ in range(5):
+            losses = step()
+    torch.cuda.synchronize()
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -51,7 +53,7 @@ def main():
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / args.steps
     tot = float(losses["total"].detach())
-    print(f"full step (eager): {n} points, {ms:.3f} ms/step, {n / ms * 1e3:.3e} points/s, "
+    print(f"full step ({'graph replay' if args.graph else 'eager'}): {n} points, {ms:.3f} ms/step, {n / ms * 1e3:.3e} points/s, "
           f"last total loss {tot:.4e}")
 
 
