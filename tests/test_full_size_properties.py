@@ -1,0 +1,82 @@
+"""BASELINE.json configurations at FULL size on the GPU, checked through size-independent properties.
+
+The oracle needs minutes for these sizes, so parity at full size is established through properties of the path:
+  * a point's residual does not depend on which other points share its launch / tile / workgroup (bit-exact),
+  * the loss sum and the weight gradient are additive over a partition of the batch,
+  * a 256-point sample of the very same launch equals the oracle (full-size network, fp64 oracle).
+Configurations come from tools/bench_configs.py (C1 .. C5 of BASELINE.json)."""
+
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _oracle_spec(tag):
+    import oracle as O
+
+    return {
+        "C1": (O.ArchSpec("fourier", hidden_dim=128, num_layers=4), O.PdeSpec(name="heat", domain=((0.0, 1.0),), parameters={"alpha": 0.01})),
+        "C2": (O.ArchSpec("fourier", hidden_dim=128, num_layers=4), O.PdeSpec(name="burgers", parameters={"nu": 0.01 / 3.141592653589793})),
+        "C3": (O.ArchSpec("resnet", hidden_dim=256, num_layers=6, num_blocks=6), O.PdeSpec(name="allen_cahn", parameters={"epsilon": 0.01})),
+        "C4": (O.ArchSpec("siren", hidden_dim=256, num_layers=8, omega_0=30.0),
+               O.PdeSpec(name="kdv", domain=((-15.0, 15.0),), time_domain=(0.0, 5.0), parameters={"speed": 1.0})),
+        "C5": (O.ArchSpec("attention", input_dim=3, hidden_dim=128, num_layers=4, activation="gelu", num_heads=4),
+               O.PdeSpec(name="cahn_hilliard", dimension=2, domain=((0.0, 1.0), (0.0, 1.0)), parameters={"epsilon": 0.01})),
+    }[tag]
+
+
+@pytest.mark.parametrize("tag", ["C1", "C2", "C3", "C4", "C5"])
+def test_full_size_configuration(tag, dev):
+    import bench_configs as B
+    import oracle as O
+    from pinnrl_amd import engine as E
+
+    name, net, eq, n_req = B.CONFIGS[tag]()
+    torch.manual_seed(1)
+    if tag == "C3":
+        x = torch.rand(n_req, 1, device=dev) * 2 - 1
+        t = torch.rand(n_req, 1, device=dev)
+    else:
+        x, t = eq.generate_collocation_points(n_req, strategy="uniform")
+    N = x.shape[0]
+    prog, pd = net.program(), eq._pde_desc()
+
+    flat = E.new_flat_grad(prog, dev)
+    r, s = E.residual_loss_grad(prog, pd, x, t, 1.0 / N, flat, want_residual=True)
+    assert torch.isfinite(r).all() and torch.isfinite(flat).all()
+
+    # (1) per-point results are independent of the launch they ride in
+    cut = (N // 3) + 5  # not a multiple of the 32-point tile
+    for lo, hi in [(0, cut), (cut, N), (N - 77, N)]:
+        r_part, _ = E.residual_forward(prog, pd, x[lo:hi], t[lo:hi])
+        assert torch.equal(r_part, r[lo:hi]), f"{tag}: rows {lo}:{hi}"
+
+    # (2) additivity over a partition of the batch (same 1/N scale)
+    fa, fb = E.new_flat_grad(prog, dev), E.new_flat_grad(prog, dev)
+    _, sa = E.residual_loss_grad(prog, pd, x[:cut], t[:cut], 1.0 / N, fa)
+    _, sb = E.residual_loss_grad(prog, pd, x[cut:], t[cut:], 1.0 / N, fb)
+    assert abs(float(sa) + float(sb) - float(s)) <= 2e-5 * abs(float(s))
+    assert rel_l2((fa + fb).cpu(), flat.cpu()) <= 1e-4  # fp32 sums of up to 1e6 terms in different orders
+    assert abs(float(s) - float((r.double() ** 2).sum())) <= 2e-5 * abs(float(s))  # the fused reduction is sum r^2
+
+    # (3) a sample of the launch against the fp64 oracle, full-size network
+    spec, pspec = _oracle_spec(tag)
+    sd = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    idx = torch.linspace(0, N - 1, 256).long()
+    xs, ts = x[idx.to(dev)].cpu().double(), t[idx.to(dev)].cpu().double()
+    r_o = O.compute_residual(pspec, lambda inp: O.network_forward(spec, sd, inp), xs, ts).detach()
+    assert rel_l2(r[idx.to(dev)].cpu(), r_o) <= 1e-5, f"{tag}: {rel_l2(r[idx.to(dev)].cpu(), r_o):.3e}"
