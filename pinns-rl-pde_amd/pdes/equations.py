@@ -156,10 +156,11 @@ class HeatEquation(PDEBase):
         boundary_loss = torch.zeros((), device=dev)
         if self.dimension == 1:
             x_lo, x_hi = self.config.domain[0]
-            jl = model.jets(torch.full((nbp, 1), x_lo, device=dev), tb, 1, 1)  # streams: u, u_t, u_x
-            jr = model.jets(torch.full((nbp, 1), x_hi, device=dev), tb, 1, 1)
-            boundary_loss = boundary_loss + self._apply_loss_fn((jl[0] - jr[0]).unsqueeze(1))
-            boundary_loss = boundary_loss + self._apply_loss_fn((jl[2] - jr[2]).unsqueeze(1))
+            # both walls in ONE jets launch (streams: u, u_t, u_x); per-point results do not depend on the batch
+            xw = torch.cat([torch.full((nbp, 1), x_lo, device=dev), torch.full((nbp, 1), x_hi, device=dev)], dim=0)
+            jw = model.jets(xw, torch.cat([tb, tb], dim=0), 1, 1)
+            boundary_loss = boundary_loss + self._apply_loss_fn((jw[0, :nbp] - jw[0, nbp:]).unsqueeze(1))
+            boundary_loss = boundary_loss + self._apply_loss_fn((jw[2, :nbp] - jw[2, nbp:]).unsqueeze(1))
         else:
             per_axis = max(nbp // (2 * self.dimension), 1)
             for axis in range(self.dimension):

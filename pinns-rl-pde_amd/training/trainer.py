@@ -95,7 +95,10 @@ class PDETrainer:
 
     def _build_adam(self, params):
         tc = self.config.training
-        return optim.Adam(params, lr=tc.learning_rate, weight_decay=tc.weight_decay)
+        # same update rule as the reference's optim.Adam(lr, weight_decay) (trainer.py:292-297); on the device the
+        # multi-tensor update runs as ONE fused kernel instead of ~10 foreach launches
+        fused = all(p.is_cuda and p.dtype == torch.float32 for p in params)
+        return optim.Adam(params, lr=tc.learning_rate, weight_decay=tc.weight_decay, fused=fused)
 
     def _build_lbfgs(self, params):
         tc, c = self.config.training, self.config.training.lbfgs
