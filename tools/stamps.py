@@ -11,11 +11,19 @@ import oracle as O
 
 NAMES = ["stage", "encode", "fwd_gemm", "fwd_ew", "out", "epi", "b0", "bwd_ew", "bwd_stream", "bwd_flush", "enc_bwd", "TOTAL", "bwd_dx", "bwd_wait"]
 dev = torch.device("cuda:0")
-cfg, model, pde = _burgers(dev, hidden=128, layers=4, mapping=32, scale=10.0)
-torch.manual_seed(1)
-n_req = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
-x, t = O.sample_uniform(O.PdeSpec(name="burgers"), n_req)
-x, t = x.to(dev), t.to(dev)
+# usage: stamps.py [N]  (headline network)   |   stamps.py C3|C4|C5  (a BASELINE configuration from bench_configs.py)
+if len(sys.argv) > 1 and sys.argv[1].startswith("C"):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as B
+    name, model, pde, n_req = B.CONFIGS[sys.argv[1]]()
+    torch.manual_seed(1)
+    x, t = pde.generate_collocation_points(n_req, strategy="uniform")
+else:
+    cfg, model, pde = _burgers(dev, hidden=128, layers=4, mapping=32, scale=10.0)
+    torch.manual_seed(1)
+    n_req = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+    x, t = O.sample_uniform(O.PdeSpec(name="burgers"), n_req)
+    x, t = x.to(dev), t.to(dev)
 prog, pd = model.program(), pde._pde_desc()
 flat = E.new_flat_grad(prog, dev)
 lib = _lib.load()
