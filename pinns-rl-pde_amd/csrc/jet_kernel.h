@@ -639,46 +639,6 @@ __device__ __forceinline__ void tape_get(f32x16 (&v)[K], const float* tape, int 
     }
 }
 
-// Deferred weight-gradient flush (NTILE == 1): the 64 atomics of a layer's dW tile row are issued 16 at a time
-// behind later MFMA work instead of back to back.  Issued as one burst they run at the memory-side atomic
-// rate (one 256-B wave instruction per ~120 cycles per CU) with every wave of the chip stalled on them.
-constexpr bool kDeferFlush = false;
-
-template <int NKT>
-struct PendingDW {
-  f32x16 acc[NKT];
-  float* base;  // dW + (32 ft + 4 lh) * in_dim + ln   (row offset of register r added at issue)
-  int in_dim;   // row stride of dW
-  int ncol;     // valid columns minus this lane's column offset: k-tile kt is written iff kt * 32 < ncol
-  int na;       // active k-tiles
-  bool live;
-};
-
-template <int NKT>
-__device__ __forceinline__ void drain_tile(PendingDW<NKT>& P, int kt_const, const f32x16& vals) {
-  if (P.live && kt_const < P.na && kt_const * 32 < P.ncol) {  // in_dim may end inside a k-tile (24 Fourier features)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      atomicAdd(P.base + (long long)((r & 3) + 8 * (r >> 2)) * P.in_dim + kt_const * 32, vals[r]);
-  }
-}
-
-// the k-tiles assigned to stream step s of K (compile-time partition of [0, NKT))
-template <int K, int NKT>
-__device__ __forceinline__ void drain_step(PendingDW<NKT>& P, int s_const) {
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    if (kt >= (s_const * NKT) / K && kt < ((s_const + 1) * NKT) / K) drain_tile<NKT>(P, kt, P.acc[kt]);
-  }
-}
-
-template <int NKT>
-__device__ __forceinline__ void drain_all(PendingDW<NKT>& P) {
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) drain_tile<NKT>(P, kt, P.acc[kt]);
-  P.live = false;
-}
-
 // sum over the 32 points of one LDS row (thread per feature)
 __device__ __forceinline__ float row_sum(const float* row) {
   float g = 0.0f;
@@ -718,8 +678,6 @@ __global__ __launch_bounds__(kThreads, OCC) void jet_kernel(const KernelArgs a) 
   float* tape = BWD ? a.tape + (long long)blockIdx.x * a.tape_stride : nullptr;
   int c = 0;  // stream-step counter: buffer parity (a buffer is rewritten two steps after it was last read)
   PINN_STAMP_DECL
-  PendingDW<NKT> pend;  // NTILE == 1: last layer's dW tile row, drained behind later MFMA work
-  pend.live = false;
 
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long p0 = tile * kT;
@@ -782,13 +740,7 @@ __global__ __launch_bounds__(kThreads, OCC) void jet_kernel(const KernelArgs a) 
         }
 #pragma unroll
         for (int jt = 0; jt < NTILE; ++jt) acc[jt][s] = accs[jt];
-        if constexpr (BWD && NTILE == 1) {
-          if (l == 0) drain_step<K, NKT>(pend, s);  // previous tile's first-layer dW
-        }
         ++c;
-      }
-      if constexpr (BWD && NTILE == 1) {
-        if (l == 0) pend.live = false;
       }
       PINN_STAMP(ST_FWD_GEMM);
       if constexpr (NTILE == 1) {
@@ -992,26 +944,13 @@ __global__ __launch_bounds__(kThreads, OCC) void jet_kernel(const KernelArgs a) 
 #pragma unroll
             for (int jt = 0; jt < NTILE; ++jt) abn[jt][s] = accs[jt];
           }
-          if constexpr (NTILE == 1) drain_step<K, NKT>(pend, s);  // the layer above's dW, 16 atomics per wave per step
           ++c;
         }
-        if constexpr (NTILE == 1) pend.live = false;
         PINN_STAMP(ST_BWD_STREAM);
-        if constexpr (NTILE == 1) {
-          if (Ly.dW && L.wave * 32 < Ly.out_dim) {
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) pend.acc[kt] = dacc[0][kt];
-            pend.base = Ly.dW + (long long)(L.wave * 32 + 4 * L.lh) * Ly.ld + L.ln;
-            pend.in_dim = Ly.ld;
-            pend.ncol = Ly.in_dim - L.ln;
-            pend.na = (Ly.in_dim + 31) >> 5;
-            pend.live = true;
-            // Measured: draining behind later MFMA work does not help — atomics share the in-order vmcnt queue
-            // with the tape / weight loads that follow, so the stall just moves.  Flush now; the real fix is
-            // fewer atomics (persistent accumulators, see jet_kernel_wide.h).
-            if constexpr (!kDeferFlush) drain_all<NKT>(pend);
-          }
-        } else if (Ly.dW) {
+        // dW tile rows: float atomics, a wave's footprint is 2 x 128-byte rows per instruction.  (Measured: draining
+        // them behind later MFMA work does not help — atomics share the in-order vmcnt queue with the tape / weight
+        // loads that follow; the real fix is fewer atomics, i.e. the wide kernel's persistent accumulators.)
+        if (Ly.dW) {
 #pragma unroll
           for (int jt = 0; jt < NTILE; ++jt) {
             const int ft = L.wave + kWaves * jt;
@@ -1087,9 +1026,6 @@ __global__ __launch_bounds__(kThreads, OCC) void jet_kernel(const KernelArgs a) 
       }
       PINN_STAMP(ST_ENC_BWD);
     }
-  }
-  if constexpr (BWD && NTILE == 1) {
-    if (pend.live) drain_all<NKT>(pend);
   }
 #ifdef PINN_STAMPS
   if (a.stamps && (tid & 63) == 0) {
