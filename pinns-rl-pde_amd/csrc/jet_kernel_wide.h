@@ -12,6 +12,7 @@
 //     workgroup (the per-tile flush ran at the memory-side atomic rate with every wave stalled on it — 27 %),
 //   * evaluates the H_last -> 1 output layer, the PDE epilogue (redundantly in all 8 lanes that own a point), the
 //     output layer's weight gradient and abar = w_out (x) ubar from registers: no LDS image of the last hidden layer,
+//     whose tape record is parked in LDS (inside the wave's own rows of the idle a_{l-1} image) instead of the slab,
 //   * has a compile-time image height (HMAX) so that every LDS access is base register + immediate offset, and
 //     pins each GEMM's operand prefetch one group ahead of its MFMAs with sched_barrier.
 // Same arithmetic, same tape layout and argument structures as jet_kernel.h; tests run both variants.
@@ -324,6 +325,38 @@ __device__ __forceinline__ void put_tile(float* img, const f32x16 (&v)[K], int h
     for (int r = 0; r < 16; ++r) img[(s * hmax + ft * 32 + acc_row(r, L.lh)) * kTP + L.ln] = v[s][r];
 }
 
+// The LAST hidden layer's tape record never goes to global memory: it is parked in LDS, inside this wave's OWN feature
+// rows of the (still unused) a_{l-1} image — 16 registers x 64 lanes = 4 KB per stream, the rows hold 4.6 KB — as
+// 16-byte words [q][lane].  The output-layer step of the reverse sweep reads it back ~100 cycles away instead of
+// ~1 us, and the wave's own replay overwrites those rows only after it has consumed the record.
+__device__ __forceinline__ float* rec_park(float* img, int hmax, int ft, int s, int q, int tid) {
+  return img + (s * hmax + ft * 32) * kTP + (q * 64 + (tid & 63)) * 4;
+}
+
+template <int ACT, int NT, int NX>
+__device__ __forceinline__ void ew_forward_park(f32x16 (&v)[1 + NT + NX], float w, float* img, int hmax, int ft, int tid) {
+  constexpr int K = 1 + NT + NX;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 rec[K];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * q + i;
+      float z[K], y[K];
+#pragma unroll
+      for (int s = 0; s < K; ++s) z[s] = v[s][r];
+      act_fwd<ACT, NT, NX>(w, z, y);
+      rec[0][i] = ActTape<ACT>::value_is_output ? y[0] : z[0];
+#pragma unroll
+      for (int s = 1; s < K; ++s) rec[s][i] = z[s];
+#pragma unroll
+      for (int s = 0; s < K; ++s) v[s][r] = y[s];
+    }
+#pragma unroll
+    for (int s = 0; s < K; ++s) *reinterpret_cast<f32x4*>(rec_park(img, hmax, ft, s, q, tid)) = rec[s];
+  }
+}
+
 // adjoint of the activation jets of accumulator register r = 4q + i, record group q given as rq[s]
 template <int ACT, int NT, int NX>
 __device__ __forceinline__ void ew_backward_q1(f32x16 (&ab)[1 + NT + NX], float w, const f32x4 (&rq)[1 + NT + NX], int r) {
@@ -527,7 +560,8 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
         }
         __syncthreads();
       } else if (on) {  // last hidden layer: its activations stay in registers (acc) for the H_last -> 1 layer
-        ew_forward<ACT, NT, NX, NTILE, BWD>(acc, Ly.act_param, tape, l, 0, tid);
+        if constexpr (BWD) ew_forward_park<ACT, NT, NX>(acc, Ly.act_param, A2, hmax, ft, tid);
+        else ew_forward<ACT, NT, NX, NTILE, false>(acc, Ly.act_param, tape, l, 0, tid);
       }
       PINN_STAMP(ST_FWD_EW);
     }
@@ -553,13 +587,6 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
       }
     }
     __syncthreads();
-    f32x4 rb0[K];  // first record group of the last hidden layer (reverse sweep, B0)
-    if constexpr (BWD) {
-      if (nl > 0) {
-#pragma unroll
-        for (int s = 0; s < K; ++s) rb0[s] = tape_ld4(tape, nl - 1, 0, 1, K, s, 0, tid);
-      }
-    }
     PINN_STAMP(ST_OUT);
 
     f32x4 rp0[K];  // first tape record group of the next replay, requested a phase ahead (reverse sweep)
@@ -607,21 +634,17 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
       if (tid < kT) pdb_out += ub[0];
       f32x16 ab[K];
       {
-        // a_{L-1} is replayed from the last layer's tape record (acc is not kept alive across the epilogue);
-        // the record groups stream one ahead, group 0 (rb0) was requested right after the barrier above
+        // a_{L-1} is replayed from the last layer's record (acc is not kept alive across the epilogue), which is
+        // parked in LDS (rec_park)
         const bool e_on = nl > 0 && ft * 32 < net.layer[nl - 1].out_dim;
         const float w_last = nl > 0 ? uniform_layer(net.layer[nl - 1]).act_param : 0.0f;
         float gr[16];
         if (e_on) {
-          f32x4 cur[K], nxt[K];
-#pragma unroll
-          for (int s = 0; s < K; ++s) cur[s] = rb0[s];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            if (q + 1 < 4) {
+            f32x4 cur[K];
 #pragma unroll
-              for (int s = 0; s < K; ++s) nxt[s] = tape_ld4(tape, nl - 1, 0, 1, K, s, q + 1, tid);
-            }
+            for (int s = 0; s < K; ++s) cur[s] = *reinterpret_cast<const f32x4*>(rec_park(A2, hmax, ft, s, q, tid));
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(wb + row4 + 8 * q);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -638,10 +661,6 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
               }
               gr[r] = g;
               ew_backward_q1<ACT, NT, NX>(ab, w_last, cur, r);
-            }
-            if (q + 1 < 4) {
-#pragma unroll
-              for (int s = 0; s < K; ++s) cur[s] = nxt[s];
             }
           }
         } else {
@@ -680,7 +699,9 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
         const bool need_abar = l > 0 || net.enc == ENC_LINEAR;
         const bool kon = ft * 32 < Ly.in_dim;  // this wave owns an input-feature tile of the layer
         float pw = 0.0f;                        // act_param of layer l-1
-        if (l + 1 < nl) __syncthreads();  // the GEMMs of layer l+1 have finished reading X (zbar) and A2
+        // the GEMMs of layer l+1 have finished reading X (zbar) and A2; with a single MFMA layer the barrier keeps
+        // encode_lds (all rows of A2, below) from overwriting another wave's parked record before its B0 has read it
+        if (l + 1 < nl || nl == 1) __syncthreads();
         PINN_STAMP(ST_BWD_PUT);
         if (on) put_tile<K>(X, ab, hmax, ft, L);
         if (l > 0) {

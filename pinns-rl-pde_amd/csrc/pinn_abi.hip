@@ -285,7 +285,7 @@ static hipError_t dispatch(int nt, int nx, const KernelArgs& a, bool bwd, int gr
   return hipErrorInvalidValue;
 }
 
-// Workgroups per CU a launch is sized (and register-budgeted) for.  PINN_OCC=1|2 overrides for experiments.
+// Workgroups per CU a launch is sized (and register-budgeted) for.  PINN_OCC=1 forces one (experiments).
 static int occupancy_for(const NetDev& n, size_t lds, bool bwd) {
   // Forward-only launches run two workgroups per CU (256 VGPRs each).  With the reverse sweep the 256-register
   // budget spills ~2000 VGPRs and one workgroup per CU is 30 % faster (KdV / siren 4x128, K = 5: 6.4 vs 8.3 ms).
@@ -298,7 +298,7 @@ static int occupancy_for(const NetDev& n, size_t lds, bool bwd) {
 }
 
 // Kernel variant: "wide" (all K streams LDS-resident, persistent dW accumulators) whenever it fits, else the
-// stream-serial kernel.  PINN_KERNEL=stream|wide overrides for experiments and tests.
+// stream-serial kernel.  PINN_KERNEL=stream forces the stream-serial kernel (tests run both variants).
 static bool use_wide(const NetDev& n, int K, bool bwd) {
   const bool fits = jet_wide_fits(K, n.hmax, bwd, n.n_layers);
   if (const char* e = getenv("PINN_KERNEL")) {
