@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_attn(const KernelArgs 
   const long long ntiles = (a.N + kT - 1) / kT;
   float* tape = BWD ? a.tape + (long long)blockIdx.x * a.tape_stride : nullptr;
   int c = 0;
+  PINN_STAMP_DECL
 
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long p0 = tile * kT;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_attn(const KernelArgs 
 
     f32x16 v[NTILE][K];
     encode_regs<ACT, NT, NX, NTILE>(net, xin, v, L);
+    PINN_STAMP(ST_ENCODE);
 
     for (int l = 0; l < nl; ++l) {
       const LayerDev LV = uniform_layer(net.layer[4 * l + 0]);
@@ -124,10 +126,12 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_attn(const KernelArgs 
 #pragma unroll
         for (int s = 0; s < K; ++s) y2[jt][s] += v[jt][s];                   // za = p + h
       if constexpr (BWD) tile_put<K, NTILE>(y2, tape, slot + 2, H, tid, L);
+      PINN_STAMP(ST_FWD_GEMM);  // value + projection Linears (and their tape stores)
       LnStats<NT, NX> Sa;
       ln_stats<NT, NX, NTILE>(y2, H, eps, red0, red1, Sa, L);
       ln_apply<NT, NX, NTILE>(y2, H, Sa, LP.ln_g, LP.ln_b, L);               // h1
       if constexpr (BWD) tile_put<K, NTILE>(y2, tape, slot + 3, H, tid, L);
+      PINN_STAMP(ST_FWD_EW);  // LayerNorm
       // feed-forward block, expansion processed in H-wide chunks; v <- zf = h1 + b_2 + sum_c W_2[:, c] gelu(W_1[c] h1 + b_1[c])
 #pragma unroll
       for (int jt = 0; jt < NTILE; ++jt)
@@ -145,9 +149,11 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_attn(const KernelArgs 
         linear_forward<K, NTILE, true>(v, y, C2, SB, sbuf, c, L);            // zf += W_2[:, c] g_c (+ b_2 once)
       }
       if constexpr (BWD) tile_put<K, NTILE>(v, tape, slot + 8, H, tid, L);
+      PINN_STAMP(ST_OUT);  // forward feed-forward chunks (8 Linear passes + GELU jets)
       LnStats<NT, NX> Sf;
       ln_stats<NT, NX, NTILE>(v, H, eps, red0, red1, Sf, L);
       ln_apply<NT, NX, NTILE>(v, H, Sf, F2.ln_g, F2.ln_b, L);                // h2
+      PINN_STAMP(ST_FWD_EW);
     }
 
     // ---- output layer ----
@@ -212,6 +218,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_attn(const KernelArgs 
       }
     }
 
+    PINN_STAMP(ST_EPI);
     if constexpr (BWD) {
       __syncthreads();
       f32x16 ab[NTILE][K];
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_attn(const KernelArgs 
         ++c;
       }
 
+      PINN_STAMP(ST_B0);
       for (int l = nl - 1; l >= 0; --l) {
         const LayerDev LV = uniform_layer(net.layer[4 * l + 0]);
         const LayerDev LP = uniform_layer(net.layer[4 * l + 1]);
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_attn(const KernelArgs 
 #pragma unroll
           for (int s = 0; s < K; ++s) acc1[jt][s] = ab[jt][s];
         tile_get<K, NTILE>(cz, tape, slot + 3, H, tid, L);  // h1, the input of every W_1 chunk
+        PINN_STAMP(ST_BWD_EW);  // LayerNorm reverse (+ parameter gradients)
         const int nchunk = F1.out_dim / H;
         for (int ch = 0; ch < nchunk; ++ch) {
           const LayerDev C1 = chunk_rows(F1, ch, H);
@@ -287,12 +296,14 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_attn(const KernelArgs 
 #pragma unroll
             for (int s = 0; s < K; ++s) acc1[jt][s] += abn[jt][s];
         }
+        PINN_STAMP(ST_BWD_STREAM);  // reverse feed-forward chunks (8 linear_backward passes + GELU replay / adjoint)
         // LN_a reverse: acc1 (= h1bar) -> zabar
         tile_get<K, NTILE>(cz, tape, slot + 2, H, tid, L);
         LnStats<NT, NX> Sa;
         ln_stats<NT, NX, NTILE>(cz, H, eps, red0, red1, Sa, L);
         ln_backward<NT, NX, NTILE>(cz, acc1, gsum, bsum, H, Sa, LP.ln_g, red0, red1, L);
         ln_param_grads<NTILE>(gsum, bsum, H, LP.d_ln_g, LP.d_ln_b, SB, sbuf, tid, L);
+        PINN_STAMP(ST_BWD_EW);
         // proj and value reverse; hbar = zabar (skip) + W_v^T W_p^T zabar
         tile_get<K, NTILE>(ap, tape, slot + 1, H, tid, L);  // v
         linear_backward<K, NTILE>(abn, acc1, ap, LP, SB, sbuf, c, tid, L);
@@ -302,6 +313,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_attn(const KernelArgs 
         for (int jt = 0; jt < NTILE; ++jt)
 #pragma unroll
           for (int s = 0; s < K; ++s) ab[jt][s] = zb[jt][s] + acc1[jt][s];
+        PINN_STAMP(ST_BWD_DX);  // projection + value linear_backward
       }
 
       // ---- input projection reverse ----
@@ -349,6 +361,12 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_attn(const KernelArgs 
       }
     }
   }
+#ifdef PINN_STAMPS
+  if (a.stamps && (tid & 63) == 0) {
+    st_acc[ST_TOTAL] = pinn_now() - st_begin;
+    for (int i = 0; i < kNumStamps; ++i) a.stamps[((long long)blockIdx.x * kWaves + L.wave) * kNumStamps + i] = st_acc[i];
+  }
+#endif
 }
 
 inline long long jet_attn_tape_floats_per_wg(int K, int n_attn_layers, int ntile) {

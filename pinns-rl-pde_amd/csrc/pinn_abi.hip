@@ -418,7 +418,9 @@ int pinn_pde_streams(const PinnPdeDesc* pde, int32_t* time_order, int32_t* space
 size_t pinn_workspace_bytes(const PinnNetDesc* net, int64_t N, int32_t time_order, int32_t space_order) {
   if (!net || N <= 0) return 0;
   // pointers are irrelevant for sizing: build the program with a dummy table
-  const float* dummy[2 * PINN_MAX_LINEAR + 2];
+  // sized for the widest weight table: attention has 16 tensors per layer (q, k, v, proj, two LayerNorms, two
+  // feed-forward Linears) — a table of 2 * PINN_MAX_LINEAR + 2 entries was overrun by a 4-layer attention network
+  const float* dummy[16 * PINN_MAX_LINEAR + 8];
   static float sixteen_aligned[4] __attribute__((aligned(16)));
   for (auto& p : dummy) p = sixteen_aligned;
   NetDev n;

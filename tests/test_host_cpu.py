@@ -46,6 +46,16 @@ def test_descriptor_queries_without_a_gpu():
     bad = E.NetProgram("fourier", "tanh", 2, [100, 1], [sd["model.fourier.B"]] + [torch.zeros(1)] * 4, [False] + [True] * 4,
                        mapping_size=32)
     assert lib.pinn_workspace_bytes(ctypes.byref(bad.desc), 100, 1, 2) == 0  # width 100: not a multiple of 32
+    # deepest weight tables: 4 attention layers = 68 tensors, 6 ResNet blocks = 52 (the sizing path once used a
+    # 50-entry scratch table); 9 tape slots per attention layer, 256 workgroups, K = 2 streams of 16 regs x 256 threads
+    import oracle as O
+    from hip_helpers import program_from_spec
+    aspec = O.ArchSpec("attention", input_dim=3, hidden_dim=128, num_layers=4, activation="gelu", num_heads=4)
+    aprog, _ = program_from_spec(aspec, O.init_state_dict(aspec, seed=0), torch.device("cpu"))
+    assert lib.pinn_workspace_bytes(ctypes.byref(aprog.desc), 1000000, 1, 0) == 9 * 4 * 2 * 16 * 256 * 4 * 256
+    rspec = O.ArchSpec("resnet", hidden_dim=256, num_layers=6, num_blocks=6)
+    rprog, _ = program_from_spec(rspec, O.init_state_dict(rspec, seed=0), torch.device("cpu"))
+    assert lib.pinn_workspace_bytes(ctypes.byref(rprog.desc), 100000, 1, 2) > 0
 
 
 def test_model_config_matches_reference_semantics():
