@@ -245,6 +245,37 @@ def test_empty_and_single_point_inputs(dev):
     assert abs(float(s1) - float(r1) ** 2) <= 1e-5 * float(r1) ** 2 + 1e-12
 
 
+@pytest.mark.parametrize("arch,num_layers", [("fourier", 2), ("feedforward", 1), ("feedforward", 2), ("siren", 1)])
+@pytest.mark.parametrize("kernel", ["default", "stream"])
+def test_shallow_networks(arch, num_layers, kernel, dev, monkeypatch):
+    """One MFMA layer (fourier with num_layers = 2, feedforward / siren with 2 hidden layers) or none at all
+    (a single hidden layer: first Linear -> output Linear): the kernels' special-cased ends, against the fp64 oracle."""
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import engine as E
+    import oracle as O
+
+    if kernel == "stream":
+        monkeypatch.setenv("PINN_KERNEL", "stream")
+    spec = O.ArchSpec(arch, hidden_dim=64, num_layers=num_layers, mapping_size=16, scale=2.0, omega_0=5.0)
+    pde = O.PdeSpec(name="burgers", parameters={"nu": 0.02})
+    sd = O.init_state_dict(spec, seed=21)
+    torch.manual_seed(22)
+    x, t = O.sample_uniform(pde, 200)
+    x, t = x[:150], t[:150]
+    r_o, L_o, g_o = O.residual_loss_and_grad(pde, spec, {k: v.double() for k, v in sd.items()}, x.double(), t.double())
+    prog, names = program_from_spec(spec, sd, dev)
+    pd = pde_desc_from_spec(pde)
+    flat = E.new_flat_grad(prog, dev)
+    r, s = E.residual_loss_grad(prog, pd, x.to(dev), t.to(dev), 1.0 / x.shape[0], flat, want_residual=True)
+    assert rel_l2(r.cpu(), r_o) <= TOL
+    assert abs(float(s) / x.shape[0] - float(L_o)) <= TOL * abs(float(L_o))
+    by_name = {n: g for n, g in zip(names, E.split_flat_grad(prog, flat)) if g is not None}
+    keys = [k for k in g_o if k in by_name]
+    got = torch.cat([by_name[k].flatten().cpu() for k in keys])
+    want = torch.cat([g_o[k].flatten() for k in keys])
+    assert rel_l2(got, want) <= TOL, f"{rel_l2(got, want):.3e}"
+
+
 def test_cpu_tensors_are_refused():
     from pinnrl_amd import engine as E
     from hip_helpers import program_from_spec
