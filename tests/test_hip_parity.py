@@ -276,6 +276,56 @@ def test_shallow_networks(arch, num_layers, kernel, dev, monkeypatch):
     assert rel_l2(got, want) <= TOL, f"{rel_l2(got, want):.3e}"
 
 
+@pytest.mark.parametrize("loss,delta", [("mse", 1.0), ("mae", 1.0), ("huber", 0.3)])
+def test_loss_functions_in_the_fused_epilogue(loss, delta, dev):
+    """PDEBase._apply_loss_fn (pde_base.py:309-326): mean r^2 / mean |r| / Huber(delta), value and gradient."""
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import engine as E
+    import oracle as O
+
+    spec, pde, sd, a, m = load_case("burgers_fourier_3x32")
+    pde = O.PdeSpec(name="burgers", parameters=pde.parameters, loss_function=loss, huber_delta=delta)
+    x, t = torch.from_numpy(a["x"]), torch.from_numpy(a["t"])
+    r_o, L_o, g_o = O.residual_loss_and_grad(pde, spec, {k: v.double() for k, v in sd.items()}, x.double(), t.double())
+    prog, names = program_from_spec(spec, sd, dev)
+    pd = pde_desc_from_spec(pde)
+    flat = E.new_flat_grad(prog, dev)
+    r, s = E.residual_loss_grad(prog, pd, x.to(dev), t.to(dev), 1.0 / x.shape[0], flat, want_residual=True)
+    assert abs(float(s) / x.shape[0] - float(L_o)) <= TOL * abs(float(L_o))
+    by_name = {n: g for n, g in zip(names, E.split_flat_grad(prog, flat)) if g is not None}
+    keys = [k for k in g_o if k in by_name]
+    got = torch.cat([by_name[k].flatten().cpu() for k in keys])
+    want = torch.cat([g_o[k].flatten() for k in keys])
+    assert rel_l2(got, want) <= 2 * TOL, f"{rel_l2(got, want):.3e}"
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky_relu"])
+def test_piecewise_linear_activations(act, dev):
+    """relu / leaky_relu (base_network.py:91-104): second derivatives vanish identically, so Burgers reduces to
+    u_t + u u_x.  Kinks: a pre-activation within rounding of zero may take the other branch than the fp64 oracle,
+    hence the looser bound on this case only."""
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import engine as E
+    import oracle as O
+
+    spec = O.ArchSpec("feedforward", hidden_dim=64, num_layers=3, activation=act)
+    pde = O.PdeSpec(name="burgers", parameters={"nu": 0.02})
+    sd = O.init_state_dict(spec, seed=31)
+    torch.manual_seed(32)
+    x, t = O.sample_uniform(pde, 200)
+    r_o, L_o, g_o = O.residual_loss_and_grad(pde, spec, {k: v.double() for k, v in sd.items()}, x.double(), t.double())
+    prog, names = program_from_spec(spec, sd, dev)
+    pd = pde_desc_from_spec(pde)
+    flat = E.new_flat_grad(prog, dev)
+    r, s = E.residual_loss_grad(prog, pd, x.to(dev), t.to(dev), 1.0 / x.shape[0], flat, want_residual=True)
+    assert rel_l2(r.cpu(), r_o) <= 1e-4
+    by_name = {n: g for n, g in zip(names, E.split_flat_grad(prog, flat)) if g is not None}
+    keys = [k for k in g_o if k in by_name]
+    got = torch.cat([by_name[k].flatten().cpu() for k in keys])
+    want = torch.cat([g_o[k].flatten() for k in keys])
+    assert rel_l2(got, want) <= 1e-4, f"{rel_l2(got, want):.3e}"
+
+
 def test_cpu_tensors_are_refused():
     from pinnrl_amd import engine as E
     from hip_helpers import program_from_spec
