@@ -326,6 +326,32 @@ def test_piecewise_linear_activations(act, dev):
     assert rel_l2(got, want) <= 1e-4, f"{rel_l2(got, want):.3e}"
 
 
+@pytest.mark.parametrize("arch,dim,pde_name", [("feedforward", 2, "heat"), ("fourier", 2, "cahn_hilliard"), ("siren", 3, "heat")])
+def test_multi_dimensional_inputs(arch, dim, pde_name, dev):
+    """input_dim 3 and 4 (x, y[, z], t) through the MLP kernels; as in the reference, every spatial term of a >= 2-D
+    residual vanishes, which the oracle reproduces."""
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import engine as E
+    import oracle as O
+
+    spec = O.ArchSpec(arch, input_dim=dim + 1, hidden_dim=64, num_layers=3, mapping_size=16, scale=2.0, omega_0=5.0)
+    pde = O.PdeSpec(name=pde_name, dimension=dim, domain=((0.0, 1.0),) * dim, parameters={"alpha": 0.05, "epsilon": 0.05})
+    sd = O.init_state_dict(spec, seed=51)
+    torch.manual_seed(52)
+    x, t = torch.rand(137, dim), torch.rand(137, 1)
+    r_o, L_o, g_o = O.residual_loss_and_grad(pde, spec, {k: v.double() for k, v in sd.items()}, x.double(), t.double())
+    prog, names = program_from_spec(spec, sd, dev)
+    pd = pde_desc_from_spec(pde)
+    flat = E.new_flat_grad(prog, dev)
+    r, s = E.residual_loss_grad(prog, pd, x.to(dev), t.to(dev), 1.0 / x.shape[0], flat, want_residual=True)
+    assert rel_l2(r.cpu(), r_o) <= TOL
+    by_name = {n: g for n, g in zip(names, E.split_flat_grad(prog, flat)) if g is not None}
+    keys = [k for k in g_o if k in by_name]
+    got = torch.cat([by_name[k].flatten().cpu() for k in keys])
+    want = torch.cat([g_o[k].flatten() for k in keys])
+    assert rel_l2(got, want) <= TOL, f"{rel_l2(got, want):.3e}"
+
+
 def test_cpu_tensors_are_refused():
     from pinnrl_amd import engine as E
     from hip_helpers import program_from_spec

@@ -106,3 +106,33 @@ def test_attention_width_256(dev):
     got = torch.cat([g[k].flatten().cpu() for k in keys])
     want = torch.cat([g_o[k].flatten() for k in keys])
     assert rel_l2(got, want) <= TOL, f"{rel_l2(got, want):.3e}"
+
+
+@pytest.mark.parametrize("arch,kw", [
+    ("fourier", dict(num_layers=3, mapping_size=32, scale=3.0)),
+    ("siren", dict(num_layers=3, omega_0=6.0)),
+    ("resnet", dict(num_layers=2, num_blocks=2, activation="tanh")),
+])
+def test_value_stream_backward_at_width_256(arch, kw, dev):
+    """The K = 1 launches behind `model(inp)` and its backward (boundary / initial terms of compute_loss): u and
+    d<c, u>/d(theta) for an arbitrary cotangent c, against torch autograd through the oracle's forward in fp64."""
+    import oracle as O
+    from hip_helpers import program_from_spec
+    from pinnrl_amd import engine as E
+
+    spec, pde, sd, x, t = _case(arch, "burgers", **kw)
+    prog, names = program_from_spec(spec, sd, dev)
+    torch.manual_seed(40)
+    cot = torch.randn(1, x.shape[0])
+    u = E.jets_forward(prog, x.to(dev), t.to(dev), 0, 0)
+    flat = E.new_flat_grad(prog, dev)
+    E.jets_backward(prog, x.to(dev), t.to(dev), 0, 0, cot.to(dev), flat)
+    params = {k: v.double().requires_grad_(k != "model.fourier.B") for k, v in sd.items()}
+    u_o = O.network_forward(spec, params, torch.cat([x, t], 1).double())
+    assert rel_l2(u[0].cpu(), u_o.detach().squeeze(1)) <= TOL
+    keys = [k for k in params if params[k].requires_grad]
+    g_o = torch.autograd.grad((u_o.squeeze(1) * cot[0].double()).sum(), [params[k] for k in keys])
+    got = {n: g for n, g in zip(names, E.split_flat_grad(prog, flat)) if g is not None}
+    a = torch.cat([got[k].flatten().cpu() for k in keys])
+    b = torch.cat([g.flatten() for g in g_o])
+    assert rel_l2(a, b) <= TOL, f"{rel_l2(a, b):.3e}"
