@@ -442,6 +442,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
   float* wb = xin + kMaxDin * kT;         // (1 + n_layers) * hmax: w_out, then the hidden-layer biases
   float* dwo = wb + (1 + net.n_layers) * hmax;  // kWaves * 4 rows * 16: dw_out partials of each 16-lane row
   float* ep = dwo + kThreads;             // (kMaxDin + 1) * hmax: encoding parameters
+  float* pl = ep + (kMaxDin + 1) * hmax;  // (kPersist + kMaxDin + 1) * hmax: per-feature db / first-Linear partials (thread tid < hmax owns feature tid)
 
   Lane L;
   L.tid = threadIdx.x;
@@ -472,12 +473,15 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
   // first kPersist layers (MFMA accumulator tiles), and per-LANE partial sums of dw_out, db, db_out and the loss
   // whose cross-lane reduction is deferred to the end — no atomics inside the tile loop.
   f32x16 pt[NPT];
-  float pdb[kPersist];       // db_l[tid]
   float pdb_out = 0.0f, ploss = 0.0f;
-  float penc[kMaxDin + 1] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // first Linear (ENC_LINEAR): d_encW[tid][:], d_encb[tid]
+  // per-thread running sums that are touched once per tile live in LDS (own slot per thread), not in VGPRs:
+  // pl[p * 256 + tid] = db_p[tid] (p < kPersist), pl[(kPersist + c) * 256 + tid] = first-Linear gradient column c / bias
   if constexpr (BWD) {
 #pragma unroll
-    for (int p = 0; p < kPersist; ++p) pdb[p] = 0.0f;
+    for (int i = 0; i < kPersist + kMaxDin + 1; ++i)
+      if (tid < hmax) pl[i * hmax + tid] = 0.0f;
+  }
+  if constexpr (BWD) {
 #pragma unroll
     for (int kt = 0; kt < NPT; ++kt)
 #pragma unroll
@@ -716,9 +720,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
         PINN_STAMP(ST_BWD_EW);
         if (Ly.db && tid < Ly.out_dim) {
           const float g = row_sum(X + tid * kTP);
-          if (l == 0) pdb[0] += g;
-          else if (l == 1) pdb[1] += g;
-          else if (l == 2) pdb[2] += g;
+          if (l < kPersist) pl[l * hmax + tid] += g;
           else atomicAdd(Ly.db + tid, g);
         }
         // abar_{l-1} = W^T zbar for all streams
@@ -785,8 +787,9 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
             if constexpr (NX >= 1) gx += X[((1 + NT) * hmax + tid) * kTP + n];
           }
 #pragma unroll
-          for (int cc = 0; cc < kMaxDin; ++cc) penc[cc] += gw[cc] + (cc == din - 1 ? gt : 0.0f) + (cc == 0 ? gx : 0.0f);
-          penc[kMaxDin] += gb;
+          for (int cc = 0; cc < kMaxDin; ++cc)
+            pl[(kPersist + cc) * hmax + tid] += gw[cc] + (cc == din - 1 ? gt : 0.0f) + (cc == 0 ? gx : 0.0f);
+          pl[(kPersist + kMaxDin) * hmax + tid] += gb;
         }
       }
       PINN_STAMP(ST_ENC_BWD);
@@ -810,8 +813,8 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
     if (net.enc == ENC_LINEAR && net.d_encW && tid < net.enc_out) {
 #pragma unroll
       for (int cc = 0; cc < kMaxDin; ++cc)
-        if (cc < din) atomicAdd(net.d_encW + tid * din + cc, penc[cc]);
-      if (net.d_encb) atomicAdd(net.d_encb + tid, penc[kMaxDin]);
+        if (cc < din) atomicAdd(net.d_encW + tid * din + cc, pl[(kPersist + cc) * hmax + tid]);
+      if (net.d_encb) atomicAdd(net.d_encb + tid, pl[(kPersist + kMaxDin) * hmax + tid]);
     }
     if (net.dw_out) {  // dwo[wave][row][r]: rows 0,1 of a wave are the two point halves of lh = 0; 2,3 of lh = 1
       const int f = ft * 32 + acc_row(tid & 15, L.lh);
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
     for (int p = 0; p < kPersist; ++p) {
       if (p < nl) {
         const LayerDev Lp = uniform_layer(net.layer[p]);
-        if (Lp.db && tid < Lp.out_dim) atomicAdd(Lp.db + tid, pdb[p]);
+        if (Lp.db && tid < Lp.out_dim) atomicAdd(Lp.db + tid, pl[p * hmax + tid]);
         if (p == 0) flush_rows<0, NA0, NPT>(pt, Lp, L);
         else if (p == 1) flush_rows<NA0, NKT, NPT>(pt, Lp, L);
         else flush_rows<NA0 + NKT, NKT, NPT>(pt, Lp, L);
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
 
 inline size_t jet_wide_lds_bytes(int K, int hmax, bool bwd, int n_layers) {
   return sizeof(float) * ((size_t)(bwd ? 2 : 1) * K * hmax * kTP + kWaves * K * kT + kMaxDin * kT + (1 + n_layers) * hmax + kThreads +
-                          (kMaxDin + 1) * hmax);
+                          (kMaxDin + 1) * hmax + (kPersist + kMaxDin + 1) * hmax);
 }
 
 // true if the wide kernel can run this problem (width <= 128, all K streams fit in LDS)
