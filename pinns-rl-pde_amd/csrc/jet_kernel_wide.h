@@ -852,40 +852,47 @@ inline bool jet_wide_fits(int K, int hmax, bool bwd, int n_layers) {
   return hmax <= 128 && jet_wide_lds_bytes(K, jet_wide_hmax(hmax), bwd, n_layers) <= 160 * 1024;
 }
 
-template <int NT, int NX>
-hipError_t launch_jet_wide(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
+// one activation's kernels (the library builds one translation unit per stream set AND activation, see the Makefile)
+template <int ACT, int NT, int NX>
+hipError_t launch_jet_wide_act(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
   constexpr int K = 1 + NT + NX;
   const int hm = jet_wide_hmax(a.net.hmax);
   const int na0 = a.net.n_layers > 0 ? (a.net.layer[0].in_dim + 31) / 32 : 4;  // k-tiles of the first MFMA layer
   const size_t lds = jet_wide_lds_bytes(K, hm, bwd, a.net.n_layers);
-  const int act = a.net.n_layers > 0 ? a.net.layer[0].act : a.net.enc_act;
   hipError_t e = hipSuccess;
-#define PINN_WLAUNCH1(ACT_, BWD_)                                                                            \
+#define PINN_WLAUNCH1(BWD_)                                                                                  \
   do {                                                                                                       \
-    auto kern = hm == 64 ? jet_kernel_wide<ACT_, NT, NX, BWD_, 64, 2>                                        \
-                : (BWD_ && na0 <= 2) ? jet_kernel_wide<ACT_, NT, NX, BWD_, 128, BWD_ ? 2 : 4>                \
-                                     : jet_kernel_wide<ACT_, NT, NX, BWD_, 128, 4>;                          \
+    auto kern = hm == 64 ? jet_kernel_wide<ACT, NT, NX, BWD_, 64, 2>                                         \
+                : (BWD_ && na0 <= 2) ? jet_kernel_wide<ACT, NT, NX, BWD_, 128, BWD_ ? 2 : 4>                 \
+                                     : jet_kernel_wide<ACT, NT, NX, BWD_, 128, 4>;                           \
     e = allow_full_lds(reinterpret_cast<const void*>(kern));                                                 \
     if (e != hipSuccess) return e;                                                                           \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, a);                                    \
   } while (0)
-#ifdef PINN_DEV
-#define PINN_WLAUNCH(BWD_) \
-  if (act == PINN_ACT_TANH) PINN_WLAUNCH1(PINN_ACT_TANH, BWD_); else return hipErrorInvalidValue;
-#else
-#define PINN_WLAUNCH(BWD_)                                                  \
-  switch (act) {                                                            \
-    case PINN_ACT_TANH: PINN_WLAUNCH1(PINN_ACT_TANH, BWD_); break;          \
-    case PINN_ACT_SIN: PINN_WLAUNCH1(PINN_ACT_SIN, BWD_); break;            \
-    case PINN_ACT_GELU: PINN_WLAUNCH1(PINN_ACT_GELU, BWD_); break;          \
-    case PINN_ACT_SIGMOID: PINN_WLAUNCH1(PINN_ACT_SIGMOID, BWD_); break;    \
-    default: PINN_WLAUNCH1(PINN_ACT_RELU, BWD_); break;                     \
-  }
-#endif
-  if (bwd) { PINN_WLAUNCH(true) } else { PINN_WLAUNCH(false) }
-#undef PINN_WLAUNCH
+  if (bwd) PINN_WLAUNCH1(true); else PINN_WLAUNCH1(false);
 #undef PINN_WLAUNCH1
   return hipGetLastError();
+}
+
+// activation id of the network -> index of the compiled activation family (piecewise-linear ones share RELU's kernels)
+inline int jet_wide_act_family(const KernelArgs& a) {
+  const int act = a.net.n_layers > 0 ? a.net.layer[0].act : a.net.enc_act;
+  return (act == PINN_ACT_TANH || act == PINN_ACT_SIN || act == PINN_ACT_GELU || act == PINN_ACT_SIGMOID) ? act : PINN_ACT_RELU;
+}
+
+// all activations from one translation unit (developer builds: tanh only)
+template <int NT, int NX>
+hipError_t launch_jet_wide(const KernelArgs& a, bool bwd, int grid, hipStream_t stream) {
+  switch (jet_wide_act_family(a)) {
+    case PINN_ACT_TANH: return launch_jet_wide_act<PINN_ACT_TANH, NT, NX>(a, bwd, grid, stream);
+#ifndef PINN_DEV
+    case PINN_ACT_SIN: return launch_jet_wide_act<PINN_ACT_SIN, NT, NX>(a, bwd, grid, stream);
+    case PINN_ACT_GELU: return launch_jet_wide_act<PINN_ACT_GELU, NT, NX>(a, bwd, grid, stream);
+    case PINN_ACT_SIGMOID: return launch_jet_wide_act<PINN_ACT_SIGMOID, NT, NX>(a, bwd, grid, stream);
+    case PINN_ACT_RELU: return launch_jet_wide_act<PINN_ACT_RELU, NT, NX>(a, bwd, grid, stream);
+#endif
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace pinn
