@@ -15,6 +15,7 @@ the imported reference on seeded inputs, then writes the vectors to
 """
 
 from .reference_path import (  # noqa: F401
+    AgentState,
     ArchSpec,
     PdeSpec,
     apply_loss_fn,
@@ -22,8 +23,15 @@ from .reference_path import (  # noqa: F401
     compute_loss_terms,
     compute_loss_terms_heat,
     compute_residual,
+    composite_layer_norm,
+    dqn_forward,
+    dqn_init_state_dict,
     init_state_dict,
+    make_agent,
     network_forward,
     residual_loss_and_grad,
+    sample_adaptive,
+    sample_stratified,
     sample_uniform,
+    select_action,
 )

@@ -180,10 +180,29 @@ def _act(name: str):
     raise ValueError(f"Unsupported activation: {name}")
 
 
-def network_forward(spec: ArchSpec, sd: Mapping[str, Tensor], inp: Tensor) -> Tensor:
-    """`PINNModel.forward` (neural_networks/__init__.py:144-154) on a state_dict."""
+def composite_layer_norm(x: Tensor, shape, weight: Tensor, bias: Tensor, eps: float = 1e-5) -> Tensor:
+    """LayerNorm written with plain mean / rsqrt ops: the same function as `F.layer_norm` (nn.LayerNorm,
+    resnet.py:43-52, feedforward.py:43-45, attention.py:36,94), but differentiated by autograd op by op.
+
+    torch 2.10's fused `layer_norm` returns a wrong THIRD derivative (double-backward of its backward), so for
+    networks with a LayerNorm the reference's d(loss)/d(theta) is not the derivative of its own loss whenever the
+    residual holds a second (or higher) input derivative.  `layer_norm="composite"` is the exact-derivative
+    checker: equal to the fused path up to second input derivatives (tests/test_oracle_golden.py) and equal to
+    finite differences for the parameter gradient."""
+    mu = x.mean(-1, keepdim=True)
+    c = x - mu
+    var = (c * c).mean(-1, keepdim=True)
+    return c * torch.rsqrt(var + eps) * weight + bias
+
+
+def network_forward(spec: ArchSpec, sd: Mapping[str, Tensor], inp: Tensor, layer_norm: str = "fused") -> Tensor:
+    """`PINNModel.forward` (neural_networks/__init__.py:144-154) on a state_dict.
+
+    `layer_norm="fused"` is the reference's op (`F.layer_norm`); `"composite"` evaluates the same LayerNorm with
+    plain ops (see `composite_layer_norm`)."""
     a = spec.architecture
     x = inp
+    LN = F.layer_norm if layer_norm == "fused" else composite_layer_norm
     if a == "fourier":
         # fourier.py:12-16 (x @ B, cat[sin, cos]); fourier.py:120-124
         proj = x @ sd["model.fourier.B"]
@@ -201,7 +220,7 @@ def network_forward(spec: ArchSpec, sd: Mapping[str, Tensor], inp: Tensor) -> Te
             x = F.linear(x, sd[f"model.layers.{idx}.weight"], sd[f"model.layers.{idx}.bias"])
             idx += 1
             if spec.layer_norm:
-                x = F.layer_norm(x, (h,), sd[f"model.layers.{idx}.weight"], sd[f"model.layers.{idx}.bias"])
+                x = LN(x, (h,), sd[f"model.layers.{idx}.weight"], sd[f"model.layers.{idx}.bias"])
                 idx += 1
             x = act(x)
             idx += 1
@@ -222,10 +241,10 @@ def network_forward(spec: ArchSpec, sd: Mapping[str, Tensor], inp: Tensor) -> Te
         for b in range(nb):
             p = f"model.blocks.{b}.layers."
             y = F.linear(x, sd[p + "0.weight"], sd[p + "0.bias"])
-            y = F.layer_norm(y, (H,), sd[p + "1.weight"], sd[p + "1.bias"])
+            y = LN(y, (H,), sd[p + "1.weight"], sd[p + "1.bias"])
             y = act(y)
             y = F.linear(y, sd[p + "4.weight"], sd[p + "4.bias"])
-            y = F.layer_norm(y, (H,), sd[p + "5.weight"], sd[p + "5.bias"])
+            y = LN(y, (H,), sd[p + "5.weight"], sd[p + "5.bias"])
             x = act(x + y)
         return F.linear(x, sd["model.output_layer.weight"], sd["model.output_layer.bias"])
     if a == "attention":
@@ -246,12 +265,12 @@ def network_forward(spec: ArchSpec, sd: Mapping[str, Tensor], inp: Tensor) -> Te
             attn = F.softmax(scores, dim=-1)
             out = torch.matmul(attn, v).transpose(1, 2).contiguous().view(bsz, 1, H)
             out = F.linear(out, sd[p + "proj.weight"], sd[p + "proj.bias"]).squeeze(1)
-            x = F.layer_norm(out + res, (H,), sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"])
+            x = LN(out + res, (H,), sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"])
             p = f"model.layers.{l}.1."
             y = F.linear(x, sd[p + "net.0.weight"], sd[p + "net.0.bias"])
             y = F.gelu(y)  # attention.py:90 — nn.GELU() regardless of config.activation
             y = F.linear(y, sd[p + "net.3.weight"], sd[p + "net.3.bias"])
-            x = F.layer_norm(x + y, (H,), sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"])
+            x = LN(x + y, (H,), sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"])
         return F.linear(x, sd["model.output_proj.weight"], sd["model.output_proj.bias"])
     raise ValueError(f"oracle: architecture '{a}' is outside the hot-path scope")
 
@@ -468,7 +487,7 @@ def apply_loss_fn(error: Tensor, name: str = "mse", huber_delta: float = 1.0) ->
 
 
 def residual_loss_and_grad(
-    pde: PdeSpec, spec: ArchSpec, sd: Mapping[str, Tensor], x: Tensor, t: Tensor
+    pde: PdeSpec, spec: ArchSpec, sd: Mapping[str, Tensor], x: Tensor, t: Tensor, layer_norm: str = "fused"
 ) -> Tuple[Tensor, Tensor, Dict[str, Tensor]]:
     """The metric's unit of work: r = compute_residual; L = mean(r^2); L.backward().
 
@@ -476,7 +495,7 @@ def residual_loss_and_grad(
     is a buffer in the reference (fourier.py:45) and gets no gradient.
     """
     params = {k: v.detach().clone().requires_grad_(k != "model.fourier.B") for k, v in sd.items()}
-    r = compute_residual(pde, lambda inp: network_forward(spec, params, inp), x, t)
+    r = compute_residual(pde, lambda inp: network_forward(spec, params, inp, layer_norm), x, t)
     L = apply_loss_fn(r, pde.loss_function, pde.huber_delta)
     names = [k for k, v in params.items() if v.requires_grad]
     grads = torch.autograd.grad(L, [params[k] for k in names], allow_unused=True)
@@ -634,3 +653,108 @@ def compute_loss_terms_heat(pde: PdeSpec, model_fn, x: Tensor, t: Tensor, num_bo
         rw, bw, iw = 1.0, 10.0, 10.0
     total = rw * residual_loss + bw * boundary_loss + iw * initial_loss
     return {"residual": residual_loss, "boundary": boundary_loss, "initial": initial_loss, "total": total}
+
+
+def sample_stratified(pde: PdeSpec, num_points: int) -> Tuple[Tensor, Tensor]:
+    """`PDEBase._sample_stratified` (pdes/pde_base.py:862-893) on CPU; consumes the global RNG identically."""
+    bounds = [tuple(pde.domain[k]) for k in range(pde.dimension)] + [tuple(pde.time_domain)]
+    samples = torch.zeros(num_points, len(bounds))
+    for d, (lo, hi) in enumerate(bounds):
+        bin_size = (hi - lo) / num_points
+        offsets = torch.rand(num_points)
+        indices = torch.arange(num_points, dtype=torch.float32)
+        samples[:, d] = lo + (indices + offsets) * bin_size
+        perm = torch.randperm(num_points)
+        samples[:, d] = samples[perm, d]
+    return samples[:, : pde.dimension], samples[:, -1].reshape(-1, 1)
+
+
+# ----------------------------------------------------------------------------
+# RL-driven ("adaptive") sampling: the DQN policy network and the epsilon-greedy scorer (row R / §8(f)2)
+# ----------------------------------------------------------------------------
+def dqn_init_state_dict(state_dim: int, action_dim: int, hidden_dim: int, num_layers: int = 3) -> Dict[str, Tensor]:
+    """theta_0 of `DQNNetwork` (pinnrl/rl/rl_agent.py:15-76) with the reference's RNG consumption order:
+    default nn.Linear draws while the Sequential is built, then `_init_weights` re-draws every Linear weight
+    with xavier_normal_ (module order) and zeroes the biases."""
+    sd: Dict[str, Tensor] = {}
+    dims = [(state_dim, hidden_dim)] + [(hidden_dim, hidden_dim)] * (num_layers - 2)
+    linear_keys = []
+    for i, (fi, fo) in enumerate(dims):
+        _linear(sd, f"layers.{i}.0", fi, fo)
+        _layernorm(sd, f"layers.{i}.1", fo)
+        linear_keys.append(f"layers.{i}.0")
+    _linear(sd, f"layers.{num_layers - 1}", hidden_dim, action_dim)
+    linear_keys.append(f"layers.{num_layers - 1}")
+    for k in linear_keys:
+        sd[k + ".weight"] = nn.init.xavier_normal_(torch.empty_like(sd[k + ".weight"]), gain=1.0)
+        sd[k + ".bias"] = torch.zeros_like(sd[k + ".bias"])
+    return sd
+
+
+def dqn_forward(sd: Mapping[str, Tensor], x: Tensor, training: bool = True, dropout: float = 0.1) -> Tensor:
+    """`DQNNetwork.forward` (rl_agent.py:78-88): (Linear, LayerNorm, ReLU, Dropout) x (L-1), Linear.
+    The reference never calls `.eval()` on the policy network, so its Dropout(0.1) is ACTIVE while scoring."""
+    n_hidden = sum(1 for k in sd if k.endswith(".0.weight"))
+    for i in range(n_hidden):
+        x = F.linear(x, sd[f"layers.{i}.0.weight"], sd[f"layers.{i}.0.bias"])
+        x = F.layer_norm(x, (x.shape[-1],), sd[f"layers.{i}.1.weight"], sd[f"layers.{i}.1.bias"])
+        x = F.dropout(F.relu(x), dropout, training)
+    return F.linear(x, sd[f"layers.{n_hidden}.weight"], sd[f"layers.{n_hidden}.bias"])
+
+
+@dataclass
+class AgentState:
+    """The fields of `RLAgent` the sampler touches (rl_agent.py:139-212): policy weights and the exploration rate."""
+
+    policy: Dict[str, Tensor]
+    epsilon: float = 1.0
+    epsilon_end: float = 0.01
+    epsilon_decay: float = 0.995
+    dropout: float = 0.1
+    training: bool = True
+
+
+def make_agent(state_dim: int, action_dim: int, hidden_dim: int, **kw) -> AgentState:
+    """`RLAgent.__init__` (rl_agent.py:139-212): builds policy_net, then target_net (a second init that only
+    advances the RNG: its weights are overwritten by the policy's)."""
+    policy = dqn_init_state_dict(state_dim, action_dim, hidden_dim)
+    dqn_init_state_dict(state_dim, action_dim, hidden_dim)  # target_net: RNG consumption only
+    return AgentState(policy=policy, **kw)
+
+
+def select_action(agent: AgentState, state: Tensor) -> Tensor:
+    """`RLAgent.select_action` (rl_agent.py:214-229).  Explore branch returns a (1, 1) tensor — with it the
+    sampler's multinomial has ONE category and every point collapses onto grid cell 0."""
+    if torch.rand(1).item() > agent.epsilon:
+        with torch.no_grad():
+            return dqn_forward(agent.policy, state, agent.training, agent.dropout).view(1, -1)
+    return torch.rand(1, 1)
+
+
+def sample_adaptive(pde: PdeSpec, num_points: int, agent: AgentState, history: List) -> Tuple[Tensor, Tensor]:
+    """The `strategy == "adaptive"` branch of `PDEBase.generate_collocation_points` (pde_base.py:961-1073)."""
+    G = min(100, max(10, int(np.sqrt(num_points))))
+    grids = [torch.linspace(pde.domain[k][0], pde.domain[k][1], G) for k in range(pde.dimension)]
+    grids.append(torch.linspace(pde.time_domain[0], pde.time_domain[1], G))
+    mesh = torch.meshgrid(*grids, indexing="ij")
+    points = torch.stack([g.flatten() for g in mesh], dim=1)
+    with torch.no_grad():
+        probs = torch.abs(select_action(agent, points))
+        probs = probs / torch.sum(probs)
+    idx = torch.multinomial(probs.flatten(), min(num_points, len(points)), replacement=True)
+    sel = points[idx]
+    if len(sel) < num_points:
+        extra = torch.randint(0, len(sel), (num_points - len(sel),))
+        sel = torch.cat([sel, sel[extra]], dim=0)
+    noise_scale = min(0.01, min((pde.domain[k][1] - pde.domain[k][0]) / G for k in range(pde.dimension)),
+                      (pde.time_domain[1] - pde.time_domain[0]) / G)
+    sel = sel + torch.randn_like(sel) * noise_scale
+    for k in range(pde.dimension):
+        sel[:, k] = torch.clamp(sel[:, k], pde.domain[k][0], pde.domain[k][1])
+    sel[:, -1] = torch.clamp(sel[:, -1], pde.time_domain[0], pde.time_domain[1])
+    x = sel[:, 0].reshape(-1, 1) if pde.dimension == 1 else sel[:, : pde.dimension]
+    t = sel[:, -1].reshape(-1, 1)
+    history.append(sel.numpy().copy())
+    if len(history) > 1:
+        agent.epsilon = max(agent.epsilon_end, agent.epsilon * agent.epsilon_decay)  # rl_agent.py:557-566
+    return x, t

@@ -400,6 +400,9 @@ class PDEBase:
             x = x + torch.randn_like(x) * ((x1 - x0) * 0.01)
             t = t + torch.randn_like(t) * ((t1 - t0) * 0.01)
             return torch.clamp(x, x0, x1), torch.clamp(t, t0, t1)
+        # >= 2-D: the reference builds the grid, the permutation and the jitter on the CPU generator and moves the
+        # result (pde_base.py:829-858); generating on `dev` keeps the step free of host copies.  On a CPU device the
+        # op sequence is the reference's, so a shared seed gives its points bit for bit (tests/test_samplers_cpu.py).
         ppd = max(2, int(num_points ** (1 / (self.dimension + 1))) + 1)
         grids = [torch.linspace(self.domain[d][0], self.domain[d][1], ppd, device=dev) for d in range(self.dimension)]
         grids.append(torch.linspace(self.time_domain[0], self.time_domain[1], ppd, device=dev))
