@@ -542,3 +542,256 @@ def attention_jets_backward(spec, sd, tape, ubar, NT, NX, eps=1e-5):
     g["model.input_proj.weight"] = sum(z0b[s].T @ a[s] for s in range(K))
     g["model.input_proj.bias"] = z0b[0].sum(0)
     return g
+
+
+# =============================================================================================================
+# General form (round 2): LayerNorm jets to any order <= 4 and the NODE PROGRAM the layer-major engine executes
+# (csrc/lm_*.h).  A network is a chain of nodes
+#       V = prologue(srcA [, skip])  ->  Y = W V + b [+ add]
+# with prologue = [LayerNorm] -> [+ skip record] -> [activation]; the head is a prologue followed by the H -> 1 dot.
+# =============================================================================================================
+def _binom(n, k):
+    return math.comb(n, k)
+
+
+def _g_derivs(v: Tensor, order: int) -> List[Tensor]:
+    """g(v) = v^(-1/2) and its derivatives g', g'', ... up to `order`."""
+    out, coef = [], 1.0
+    for n in range(order + 1):
+        out.append(coef * v ** (-(2 * n + 1) / 2))
+        coef *= -(2 * n + 1) / 2
+    return out
+
+
+def _ln_dir_stats(c0, cs, v0):
+    """One direction: moments v_k = sum_i C(k,i) mean(c_i c_{k-i}) and r_k = d^k/dt^k (v^-1/2), k = 1..m."""
+    m = len(cs)
+    c = [c0] + list(cs)
+    v = [sum(_binom(k, i) * (c[i] * c[k - i]).mean(-1, keepdim=True) for i in range(k + 1)) for k in range(1, m + 1)]
+    g = _g_derivs(v0, max(m, 1))
+    r = _dir_fwd(g, v)
+    return v, r
+
+
+def ln_fwd_gen(z: List[Tensor], gamma, beta, eps: float, NT: int, NX: int) -> List[Tensor]:
+    c = [s - s.mean(-1, keepdim=True) for s in z]
+    v0 = (c[0] * c[0]).mean(-1, keepdim=True) + eps
+    r0 = v0**-0.5
+    out = [c[0] * r0 * gamma + beta]
+    for lo, m in ((1, NT), (1 + NT, NX)):
+        cs = c[lo : lo + m]
+        _, r = _ln_dir_stats(c[0], cs, v0)
+        rr = [r0] + r
+        cc = [c[0]] + cs
+        for k in range(1, m + 1):
+            out.append(gamma * sum(_binom(k, i) * cc[i] * rr[k - i] for i in range(k + 1)))
+    return out
+
+
+def ln_bwd_gen(z: List[Tensor], yb: List[Tensor], gamma, eps: float, NT: int, NX: int):
+    """Adjoint of ln_fwd_gen: (zbar streams, dgamma, dbeta)."""
+    K = 1 + NT + NX
+    H = z[0].shape[-1]
+    S = lambda t: t.sum(-1, keepdim=True)  # noqa: E731
+    c = [s - s.mean(-1, keepdim=True) for s in z]
+    v0 = (c[0] * c[0]).mean(-1, keepdim=True) + eps
+    r0 = v0**-0.5
+    hb = [gamma * yb[s] for s in range(K)]  # yhat-bar
+    yhat0 = c[0] * r0
+    dgamma = (yb[0] * yhat0).sum(0)
+    dbeta = yb[0].sum(0)
+    cb = [torch.zeros_like(c[0]) for _ in range(K)]
+    cb[0] = cb[0] + r0 * hb[0]
+    r0b = S(c[0] * hb[0])
+    v0b_extra = torch.zeros_like(v0)
+    for lo, m in ((1, NT), (1 + NT, NX)):
+        if m == 0:
+            continue
+        cs = c[lo : lo + m]
+        cc = [c[0]] + cs
+        v, r = _ln_dir_stats(c[0], cs, v0)
+        rr = [r0] + r
+        hbd = [None] + hb[lo : lo + m]
+        for k in range(1, m + 1):
+            yk = sum(_binom(k, i) * cc[i] * rr[k - i] for i in range(k + 1))
+            dgamma = dgamma + (yb[lo + k - 1] * yk).sum(0)
+        # cbar_i += sum_{k>=i} C(k,i) r_{k-i} hb_k ;  rbar_j = sum_{k>=j} C(k,j) S(c_{k-j} hb_k)
+        rb = [torch.zeros_like(v0) for _ in range(m + 1)]
+        for k in range(1, m + 1):
+            for i in range(k + 1):
+                idx = 0 if i == 0 else lo + i - 1
+                cb[idx] = cb[idx] + _binom(k, i) * rr[k - i] * hbd[k]
+                rb[k - i] = rb[k - i] + _binom(k, i) * S(cc[i] * hbd[k])
+        r0b = r0b + rb[0]
+        g = _g_derivs(v0, m + 1)
+        z0b, vb = _dir_bwd(g, v, rb[1:])
+        v0b_extra = v0b_extra + z0b
+        # cbar_i += sum_{k>=max(i,1)} vbar_k * 2 C(k,i) c_{k-i} / H
+        for k in range(1, m + 1):
+            for i in range(k + 1):
+                idx = 0 if i == 0 else lo + i - 1
+                cb[idx] = cb[idx] + vb[k - 1] * (2.0 * _binom(k, i) / H) * cc[k - i]
+    v0b = -0.5 * v0**-1.5 * r0b + v0b_extra
+    cb[0] = cb[0] + v0b * (2.0 / H) * c[0]
+    zb = [t - t.mean(-1, keepdim=True) for t in cb]
+    return zb, dgamma, dbeta
+
+
+def net_program(spec, sd: Mapping[str, Tensor]) -> Dict:
+    """The node list of an architecture (what csrc/lm_program.h builds from a PinnNetDesc)."""
+    a = spec.architecture
+    nodes: List[Dict] = []
+
+    def lin(name):
+        return {"W": sd[name + ".weight"], "b": sd[name + ".bias"], "name": name}
+
+    def ln(name):
+        return {"g": sd[name + ".weight"], "b": sd[name + ".bias"], "name": name}
+
+    if a in ("feedforward", "siren"):
+        hs = spec.dims()
+        if a == "siren":
+            names = [f"model.layers.{i}.linear" for i in range(len(hs))] + [f"model.layers.{len(hs)}"]
+            lns = [None] * len(hs)
+            act, par = "sin", spec.omega_0
+        else:
+            step = 3 if spec.layer_norm else 2
+            names = [f"model.layers.{step * i}" for i in range(len(hs) + 1)]
+            lns = [ln(f"model.layers.{step * i + 1}") if spec.layer_norm else None for i in range(len(hs))]
+            act, par = spec.activation, 0.0
+        enc = lin(names[0])
+        src = {"kind": "coords_linear", "enc": enc}
+        for i in range(1, len(hs)):
+            nodes.append({"src": src, "ln": lns[i - 1], "skip": None, "act": (act, par), "lin": lin(names[i]), "add": None})
+            src = {"kind": "rec", "node": len(nodes) - 1}
+        head = {"src": src, "ln": lns[-1], "skip": None, "act": (act, par), "lin": lin(names[-1])}
+    elif a == "fourier":
+        n = spec.num_layers
+        src = {"kind": "coords_fourier", "B": sd["model.fourier.B"]}
+        for i in range(n - 1):
+            nodes.append({"src": src, "ln": None, "skip": None, "act": None if i == 0 else (spec.activation, 0.0),
+                          "lin": lin(f"model.layers.{i}"), "add": None})
+            src = {"kind": "rec", "node": len(nodes) - 1}
+        head = {"src": src, "ln": None, "skip": None, "act": (spec.activation, 0.0) if n > 1 else None,
+                "lin": lin(f"model.layers.{n - 1}")}
+    elif a == "resnet":
+        nb = spec.num_blocks if spec.num_blocks is not None else spec.num_layers
+        act = (spec.activation, 0.0)
+        src, lnq, skip = {"kind": "coords_linear", "enc": lin("model.input_layer")}, None, None
+        for b in range(nb):
+            p = f"model.blocks.{b}.layers."
+            nodes.append({"src": src, "ln": lnq, "skip": skip, "act": act, "lin": lin(p + "0"), "add": None})
+            n1 = len(nodes) - 1
+            nodes.append({"src": {"kind": "rec", "node": n1}, "ln": ln(p + "1"), "skip": None, "act": act,
+                          "lin": lin(p + "4"), "add": None})
+            src, lnq, skip = {"kind": "rec", "node": len(nodes) - 1}, ln(p + "5"), n1  # q_b = LN2(z2_b) + V(n1_b)
+        head = {"src": src, "ln": lnq, "skip": skip, "act": act, "lin": lin("model.output_layer")}
+    elif a == "attention":
+        src, lnq, act = {"kind": "coords_linear", "enc": lin("model.input_proj")}, None, (spec.activation, 0.0)
+        for l in range(spec.num_layers):
+            pa, pf = f"model.layers.{l}.0.", f"model.layers.{l}.1."
+            nodes.append({"src": src, "ln": lnq, "skip": None, "act": act, "lin": lin(pa + "value"), "add": None})
+            nv = len(nodes) - 1
+            nodes.append({"src": {"kind": "rec", "node": nv}, "ln": None, "skip": None, "act": None, "lin": lin(pa + "proj"),
+                          "add": nv})  # za = W_p v + b_p + h
+            nodes.append({"src": {"kind": "rec", "node": len(nodes) - 1}, "ln": ln(pa + "layer_norm"), "skip": None,
+                          "act": None, "lin": lin(pf + "net.0"), "add": None})
+            n1 = len(nodes) - 1
+            nodes.append({"src": {"kind": "rec", "node": n1}, "ln": None, "skip": None, "act": ("gelu", 0.0),
+                          "lin": lin(pf + "net.3"), "add": n1})  # zf = W_2 gelu(z1) + b_2 + h1
+            src, lnq, act = {"kind": "rec", "node": len(nodes) - 1}, ln(pf + "layer_norm"), None
+        head = {"src": src, "ln": lnq, "skip": None, "act": act, "lin": lin("model.output_proj")}
+    else:
+        raise ValueError(a)
+    return {"nodes": nodes, "head": head}
+
+
+def _source_jets(src, inp, Y, NT, NX):
+    K = 1 + NT + NX
+    if src["kind"] == "rec":
+        return Y[src["node"]]
+    a = input_streams(inp, NT, NX)
+    if src["kind"] == "coords_linear":
+        return _lin(a, src["enc"]["W"], src["enc"]["b"], K)
+    z = [s @ src["B"] for s in a]  # fourier features: [sin, cos] jets of the projection
+    sin_j = act_fwd("sin", 1.0, z, NT, NX)
+    cos_j = act_fwd("sin", 1.0, [z[0] + math.pi / 2] + z[1:], NT, NX)
+    return [torch.cat([s, c], -1) for s, c in zip(sin_j, cos_j)]
+
+
+def _prologue_fwd(node, inp, Y, V, NT, NX, eps):
+    K = 1 + NT + NX
+    p = _source_jets(node["src"], inp, Y, NT, NX)
+    if node["ln"] is not None:
+        p = ln_fwd_gen(p, node["ln"]["g"], node["ln"]["b"], eps, NT, NX)
+    if node["skip"] is not None:
+        p = [p[s] + V[node["skip"]][s] for s in range(K)]
+    if node["act"] is not None:
+        return act_fwd(node["act"][0], node["act"][1], p, NT, NX), p
+    return p, p
+
+
+def program_forward(prog, inp, NT, NX, eps=1e-5):
+    K = 1 + NT + NX
+    Y, V, P = [], [], []
+    for node in prog["nodes"]:
+        v, p = _prologue_fwd(node, inp, Y, V, NT, NX, eps)
+        y = _lin(v, node["lin"]["W"], node["lin"]["b"], K)
+        if node["add"] is not None:
+            y = [y[s] + V[node["add"]][s] for s in range(K)]
+        V.append(v)
+        P.append(p)
+        Y.append(y)
+    vh, ph = _prologue_fwd(prog["head"], inp, Y, V, NT, NX, eps)
+    u = _lin(vh, prog["head"]["lin"]["W"], prog["head"]["lin"]["b"], K)
+    return u, {"inp": inp, "Y": Y, "V": V, "P": P, "vh": vh, "ph": ph}
+
+
+def _prologue_bwd(node, tape, vbar, pre, NT, NX, eps, g, extra):
+    """vbar: cotangent of the prologue's output.  Routes cotangents to the source record / encoder and the skip."""
+    K = 1 + NT + NX
+    inp, Y, V = tape["inp"], tape["Y"], tape["V"]
+    pb = act_bwd(node["act"][0], node["act"][1], pre, vbar, NT, NX) if node["act"] is not None else vbar
+    if node["skip"] is not None:
+        extra[node["skip"]] = [extra[node["skip"]][s] + pb[s] for s in range(K)] if node["skip"] in extra else list(pb)
+    src = node["src"]
+    if node["ln"] is not None:
+        zsrc = _source_jets(src, inp, Y, NT, NX)
+        pb, dg, db = ln_bwd_gen(zsrc, pb, node["ln"]["g"], eps, NT, NX)
+        g[node["ln"]["name"] + ".weight"], g[node["ln"]["name"] + ".bias"] = dg, db
+    if src["kind"] == "rec":
+        return pb  # = zbar of node src["node"]
+    if src["kind"] == "coords_linear":
+        a = input_streams(inp, NT, NX)
+        g[src["enc"]["name"] + ".weight"] = sum(pb[s].T @ a[s] for s in range(K))
+        g[src["enc"]["name"] + ".bias"] = pb[0].sum(0)
+    return None
+
+
+def program_backward(prog, tape, ubar, NT, NX, eps=1e-5):
+    K = 1 + NT + NX
+    g: Dict[str, Tensor] = {}
+    extra: Dict[int, List[Tensor]] = {}  # additional cotangents of V records (skip connections, epilogue adds)
+    hd = prog["head"]
+    g[hd["lin"]["name"] + ".weight"] = sum(ubar[s].T @ tape["vh"][s] for s in range(K))
+    g[hd["lin"]["name"] + ".bias"] = ubar[0].sum(0)
+    vbar = [ubar[s] @ hd["lin"]["W"] for s in range(K)]
+    zbar = {}
+    zb = _prologue_bwd(hd, tape, vbar, tape["ph"], NT, NX, eps, g, extra)
+    if zb is not None:
+        zbar[hd["src"]["node"]] = zb
+    for m in range(len(prog["nodes"]) - 1, -1, -1):
+        node = prog["nodes"][m]
+        zb = zbar[m]
+        if node["add"] is not None:
+            extra[node["add"]] = [extra[node["add"]][s] + zb[s] for s in range(K)] if node["add"] in extra else list(zb)
+        nm = node["lin"]["name"]
+        g[nm + ".weight"] = sum(zb[s].T @ tape["V"][m][s] for s in range(K))
+        g[nm + ".bias"] = zb[0].sum(0)
+        vbar = [zb[s] @ node["lin"]["W"] for s in range(K)]
+        if m in extra:
+            vbar = [vbar[s] + extra[m][s] for s in range(K)]
+        zprev = _prologue_bwd(node, tape, vbar, tape["P"][m], NT, NX, eps, g, extra)
+        if zprev is not None:
+            zbar[node["src"]["node"]] = zprev
+    return g
