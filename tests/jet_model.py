@@ -795,3 +795,10 @@ def program_backward(prog, tape, ubar, NT, NX, eps=1e-5):
         if zprev is not None:
             zbar[node["src"]["node"]] = zprev
     return g
+
+
+# the order <= 2 LayerNorm formulas above are the special case the round-1 kernels implemented; every caller now goes
+# through the general form
+ln_fwd = ln_fwd_gen
+ln_fwd2 = ln_fwd_gen
+ln_bwd = ln_bwd_gen

@@ -122,7 +122,7 @@ def test_resnet_jets_and_gradient_match_autograd(tag):
     jets, tape = J.resnet_jets_forward(spec, sd, torch.cat([x, t], 1), NT, NX)
     assert rel_l2(jets[0], a["u64"]) < 1e-12
     r, dr = J.pde_residual(pde.name, pde.parameters, jets, x[:, 0:1], NT, NX, pde.dimension)
-    assert rel_l2(r, a["residual64"]) < 1e-9  # residual (u, u_t, u_xx) matches the reference
+    assert rel_l2(r, a["residual64_exact"]) < 1e-9  # == the reference's residual while it chains <= 2 differentiations
     N = x.shape[0]
     g = J.resnet_jets_backward(spec, sd, tape, [2.0 * r / N * d for d in dr], NT, NX)
     flat = torch.cat([g[k].flatten() for k in m["param_names"]])
@@ -132,8 +132,9 @@ def test_resnet_jets_and_gradient_match_autograd(tag):
     r2, _ = J.pde_residual(pde.name, pde.parameters, jets2, x[:, 0:1], NT, NX, pde.dimension)
     exact = torch.autograd.grad((r2**2).mean(), [sdg[k] for k in m["param_names"]])
     assert rel_l2(flat, torch.cat([e.flatten() for e in exact])) < 1e-10
-    # the reference's own gradient carries torch's fused-LayerNorm error, scaled here by eps^2 = 1e-4 (u_xx weight)
-    assert rel_l2(flat, a["grad64"]) < 5e-4
+    assert rel_l2(flat, a["grad64_exact"]) < 1e-9  # the oracle's composite-LayerNorm gradient (pinned by make_golden.py)
+    if pde.name == "allen_cahn":  # witness: the reference's gradient carries torch's fused-LayerNorm error x eps^2
+        assert rel_l2(flat, a["grad64"]) < 5e-4
 
 
 def test_attention_jets_and_gradient_match_reference():
