@@ -40,9 +40,16 @@
 extern "C" {
 #endif
 
-#define PINN_ABI_VERSION 1
+#define PINN_ABI_VERSION 2
 #define PINN_MAX_LINEAR 24
 #define PINN_MAX_STREAMS 7 /* value + up to 2 time + up to 4 space derivatives */
+
+/* PinnNetDesc.flags */
+#define PINN_FLAG_LAYER_NORM 1    /* feedforward: a LayerNorm follows every hidden Linear (feedforward.py:43-45) */
+#define PINN_FLAG_DETERMINISTIC 2 /* weight gradients reduced in a fixed order: two launches on the same inputs give
+                                     bit-identical gradients (reference anchor: tests/unit_tests/test_benchmarks.py:61-64) */
+#define PINN_FLAG_LAYER_MAJOR 4   /* engine hint: run the layer-major engine even where the fused tile-major kernel
+                                     applies (same results to rounding; tests run both) */
 
 typedef enum PinnStatus {
   PINN_OK = 0,
@@ -55,7 +62,7 @@ typedef enum PinnStatus {
 } PinnStatus;
 
 typedef enum PinnArch {
-  PINN_ARCH_FEEDFORWARD = 0, /* feedforward.py:9-73 (layer_norm = False) */
+  PINN_ARCH_FEEDFORWARD = 0, /* feedforward.py:9-73 (PINN_FLAG_LAYER_NORM: Linear, LayerNorm, act per hidden layer) */
   PINN_ARCH_FOURIER = 1,     /* fourier.py:65-124 */
   PINN_ARCH_SIREN = 2,       /* siren.py:49-90 */
   PINN_ARCH_RESNET = 3,      /* resnet.py:68-142 */
@@ -92,12 +99,12 @@ typedef struct PinnNetDesc {
   int32_t activation;              /* PinnAct of the hidden layers */
   int32_t input_dim;               /* spatial dimension + 1 */
   int32_t num_linear;              /* Linear layers including the output layer */
-  int32_t widths[PINN_MAX_LINEAR]; /* out_features of each Linear; widths[num_linear-1] must be 1 */
+  int32_t widths[PINN_MAX_LINEAR]; /* out_features of each Linear (1 .. 1024, any value); widths[num_linear-1] must be 1 */
   int32_t mapping_size;            /* fourier: columns of B (features = 2 * mapping_size) */
   float act_param;                 /* omega_0 for PINN_ACT_SIN */
   float ln_eps;                    /* LayerNorm epsilon (resnet / attention) */
   int32_t num_blocks;              /* resnet blocks / attention layers */
-  int32_t flags;                   /* reserved, 0 */
+  int32_t flags;                   /* PINN_FLAG_* */
 } PinnNetDesc;
 
 typedef struct PinnPdeDesc {
@@ -111,41 +118,58 @@ typedef struct PinnPdeDesc {
 int pinn_abi_version(void);
 const char* pinn_last_error(void);
 
+/* How the library was built: one line per kernel translation unit that did not build in its preferred form
+ * (see csrc/Makefile), or "" — so that a degraded build is visible to callers, tests and the bench line. */
+const char* pinn_build_info(void);
+
+/* Number of tensors the reference's state_dict holds for this descriptor — the length every `weights` /
+ * `weight_grads` table passed below must have (`num_tensors`).  Negative PinnStatus on a bad descriptor. */
+int pinn_num_tensors(const PinnNetDesc* net);
+
 /* (time_order, space_order) of the jet streams a PDE's residual consumes; K = 1 + nt + nx. */
 int pinn_pde_streams(const PinnPdeDesc* pde, int32_t* time_order, int32_t* space_order);
 
-/* Bytes of scratch the backward entry points need for N points (0 for forward-only calls). */
-size_t pinn_workspace_bytes(const PinnNetDesc* net, int64_t N, int32_t time_order, int32_t space_order);
+/* Bytes of scratch a call on N points needs (`backward` = 0 for the forward-only entry points, 1 otherwise).
+ * Zero is a valid answer (small networks run from registers and LDS alone); 0 is also returned for a descriptor the
+ * library cannot run — the compute entry points then report why. */
+size_t pinn_workspace_bytes(const PinnNetDesc* net, int64_t N, int32_t time_order, int32_t space_order, int32_t backward);
+
+/* Every compute entry point: `weights` (and `weight_grads`) are tables of `num_tensors` device pointers in the
+ * reference's state_dict order; the count is validated against the descriptor BEFORE any entry is read.
+ * `workspace` must hold pinn_workspace_bytes(...) bytes, 16-byte aligned (may be NULL when that is 0). */
 
 /* jets_out[s] : N floats each, stream order [u, d/dt.., d/dx..]; all K = 1+nt+nx entries required. */
-int pinn_jet_forward(const PinnNetDesc* net, const float* const* weights, const float* x, const float* t,
-                     int64_t N, int32_t time_order, int32_t space_order, float* const* jets_out, void* stream);
+int pinn_jet_forward(const PinnNetDesc* net, const float* const* weights, int32_t num_tensors, const float* x,
+                     const float* t, int64_t N, int32_t time_order, int32_t space_order, float* const* jets_out,
+                     void* workspace, size_t ws_bytes, void* stream);
 
-/* Recomputes the forward per tile (tape in `workspace`), then accumulates
+/* Recomputes the forward, then accumulates
  * d(sum_s sum_n jet_cotangents[s][n] * jet_s[n]) / d(weights) into weight_grads (+=). */
-int pinn_jet_backward(const PinnNetDesc* net, const float* const* weights, const float* x, const float* t,
-                      int64_t N, int32_t time_order, int32_t space_order, const float* const* jet_cotangents,
-                      float* const* weight_grads, void* workspace, size_t ws_bytes, void* stream);
+int pinn_jet_backward(const PinnNetDesc* net, const float* const* weights, int32_t num_tensors, const float* x,
+                      const float* t, int64_t N, int32_t time_order, int32_t space_order,
+                      const float* const* jet_cotangents, float* const* weight_grads, void* workspace, size_t ws_bytes,
+                      void* stream);
 
 /* residual_out: N floats or NULL.  loss_sum_out: 1 float or NULL; receives += sum_n l(r_n)
  * (l = r^2 | |r| | huber), i.e. the UNnormalised loss — the caller divides by the global N. */
-int pinn_residual_forward(const PinnNetDesc* net, const float* const* weights, const PinnPdeDesc* pde,
-                          const float* x, const float* t, int64_t N, float* residual_out, float* loss_sum_out,
-                          void* stream);
+int pinn_residual_forward(const PinnNetDesc* net, const float* const* weights, int32_t num_tensors,
+                          const PinnPdeDesc* pde, const float* x, const float* t, int64_t N, float* residual_out,
+                          float* loss_sum_out, void* workspace, size_t ws_bytes, void* stream);
 
-/* One launch: residual, loss sum, and weight_grads += grad_scale * d(sum_n l(r_n))/d(weights).
+/* One call: residual, loss sum, and weight_grads += grad_scale * d(sum_n l(r_n))/d(weights).
  * For mean-squared loss over N_total points use grad_scale = upstream / N_total. */
-int pinn_residual_loss_grad(const PinnNetDesc* net, const float* const* weights, const PinnPdeDesc* pde,
-                            const float* x, const float* t, int64_t N, float grad_scale, float* residual_out,
-                            float* loss_sum_out, float* const* weight_grads, void* workspace, size_t ws_bytes,
-                            void* stream);
+int pinn_residual_loss_grad(const PinnNetDesc* net, const float* const* weights, int32_t num_tensors,
+                            const PinnPdeDesc* pde, const float* x, const float* t, int64_t N, float grad_scale,
+                            float* residual_out, float* loss_sum_out, float* const* weight_grads, void* workspace,
+                            size_t ws_bytes, void* stream);
 
 /* weight_grads += d(sum_n residual_cotangent[n] * r_n)/d(weights): the backward of pinn_residual_forward for an
  * arbitrary downstream graph (loss.backward() through `residual`, trainer.py:689; LRW's per-component
  * backward passes, trainer.py:607-626). */
-int pinn_residual_backward(const PinnNetDesc* net, const float* const* weights, const PinnPdeDesc* pde,
-                           const float* x, const float* t, int64_t N, const float* residual_cotangent,
-                           float* const* weight_grads, void* workspace, size_t ws_bytes, void* stream);
+int pinn_residual_backward(const PinnNetDesc* net, const float* const* weights, int32_t num_tensors,
+                           const PinnPdeDesc* pde, const float* x, const float* t, int64_t N,
+                           const float* residual_cotangent, float* const* weight_grads, void* workspace,
+                           size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

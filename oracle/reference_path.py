@@ -468,6 +468,9 @@ def compute_residual(pde: PdeSpec, model_fn, x: Tensor, t: Tensor) -> Tensor:
         xd = d["_x"]
         V = model_fn(torch.cat([xd, d["_t"]], dim=1))
         sigma, r = p.get("sigma", 0.2), p.get("r", 0.05)
+        if dim > 1:  # black_scholes.py:84-91: first-dimension derivatives (zeros: fresh-slice quirk) broadcast over x
+            return (d["dt"] + 0.5 * sigma**2 * torch.sum(xd**2 * d["dx1x1"], dim=1, keepdim=True)
+                    + r * torch.sum(xd * d["dx1"], dim=1, keepdim=True) - r * V)
         return d["dt"] + 0.5 * sigma**2 * xd**2 * d["dx2"] + r * xd * d["dx"] - r * V
     if name == "pendulum":  # pendulum_equation.py:51-94
         d = compute_derivatives(model_fn, x, t, temporal_derivatives=[1, 2], spatial_derivatives=set(), dimension=dim)

@@ -11,9 +11,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PINN_LIB") or os.path.join(_HERE, "libpinnjet.so")  # PINN_LIB: developer builds
 CSRC = os.path.join(_HERE, "csrc")
 
-PINN_ABI_VERSION = 1
+PINN_ABI_VERSION = 2
 PINN_MAX_LINEAR = 24
 PINN_MAX_STREAMS = 7
+PINN_FLAG_LAYER_NORM = 1
+PINN_FLAG_DETERMINISTIC = 2
+PINN_FLAG_LAYER_MAJOR = 4
 
 ARCH = {"feedforward": 0, "fourier": 1, "siren": 2, "resnet": 3, "attention": 4}
 ACT = {"tanh": 0, "sin": 1, "gelu": 2, "sigmoid": 3, "relu": 4, "leaky_relu": 5, "identity": 6}
@@ -24,8 +27,9 @@ PDE = {
 LOSS = {"mse": 0, "mae": 1, "huber": 2}
 
 EXPORTS = (
-    "pinn_abi_version", "pinn_last_error", "pinn_pde_streams", "pinn_workspace_bytes", "pinn_jet_forward",
-    "pinn_jet_backward", "pinn_residual_forward", "pinn_residual_backward", "pinn_residual_loss_grad",
+    "pinn_abi_version", "pinn_last_error", "pinn_build_info", "pinn_num_tensors", "pinn_pde_streams",
+    "pinn_workspace_bytes", "pinn_jet_forward", "pinn_jet_backward", "pinn_residual_forward", "pinn_residual_backward",
+    "pinn_residual_loss_grad",
 )
 
 
@@ -86,27 +90,36 @@ def load():
         lib.pinn_abi_version.argtypes = []
         lib.pinn_last_error.restype = ctypes.c_char_p
         lib.pinn_last_error.argtypes = []
+        lib.pinn_build_info.restype = ctypes.c_char_p
+        lib.pinn_build_info.argtypes = []
+        lib.pinn_num_tensors.restype = ctypes.c_int
+        lib.pinn_num_tensors.argtypes = [P(PinnNetDesc)]
         lib.pinn_pde_streams.restype = ctypes.c_int
         lib.pinn_pde_streams.argtypes = [P(PinnPdeDesc), P(i32), P(i32)]
         lib.pinn_workspace_bytes.restype = ctypes.c_size_t
-        lib.pinn_workspace_bytes.argtypes = [P(PinnNetDesc), i64, i32, i32]
+        lib.pinn_workspace_bytes.argtypes = [P(PinnNetDesc), i64, i32, i32, i32]
+        sz = ctypes.c_size_t
         lib.pinn_jet_forward.restype = ctypes.c_int
-        lib.pinn_jet_forward.argtypes = [P(PinnNetDesc), P(vp), vp, vp, i64, i32, i32, P(vp), vp]
+        lib.pinn_jet_forward.argtypes = [P(PinnNetDesc), P(vp), i32, vp, vp, i64, i32, i32, P(vp), vp, sz, vp]
         lib.pinn_jet_backward.restype = ctypes.c_int
-        lib.pinn_jet_backward.argtypes = [P(PinnNetDesc), P(vp), vp, vp, i64, i32, i32, P(vp), P(vp), vp,
-                                          ctypes.c_size_t, vp]
+        lib.pinn_jet_backward.argtypes = [P(PinnNetDesc), P(vp), i32, vp, vp, i64, i32, i32, P(vp), P(vp), vp, sz, vp]
         lib.pinn_residual_forward.restype = ctypes.c_int
-        lib.pinn_residual_forward.argtypes = [P(PinnNetDesc), P(vp), P(PinnPdeDesc), vp, vp, i64, vp, vp, vp]
+        lib.pinn_residual_forward.argtypes = [P(PinnNetDesc), P(vp), i32, P(PinnPdeDesc), vp, vp, i64, vp, vp, vp, sz, vp]
         lib.pinn_residual_backward.restype = ctypes.c_int
-        lib.pinn_residual_backward.argtypes = [P(PinnNetDesc), P(vp), P(PinnPdeDesc), vp, vp, i64, vp, P(vp), vp,
-                                               ctypes.c_size_t, vp]
+        lib.pinn_residual_backward.argtypes = [P(PinnNetDesc), P(vp), i32, P(PinnPdeDesc), vp, vp, i64, vp, P(vp), vp, sz,
+                                               vp]
         lib.pinn_residual_loss_grad.restype = ctypes.c_int
-        lib.pinn_residual_loss_grad.argtypes = [P(PinnNetDesc), P(vp), P(PinnPdeDesc), vp, vp, i64, f32, vp, vp,
-                                                P(vp), vp, ctypes.c_size_t, vp]
+        lib.pinn_residual_loss_grad.argtypes = [P(PinnNetDesc), P(vp), i32, P(PinnPdeDesc), vp, vp, i64, f32, vp, vp,
+                                                P(vp), vp, sz, vp]
         if lib.pinn_abi_version() != PINN_ABI_VERSION:
             raise JetLibraryError(f"libpinnjet.so ABI {lib.pinn_abi_version()} != expected {PINN_ABI_VERSION}: rebuild")
         _lib = lib
     return _lib
+
+
+def build_info() -> str:
+    """Kernel translation units that were built in a degraded form ('' when none), see csrc/Makefile."""
+    return load().pinn_build_info().decode("utf-8", "replace")
 
 
 def check(rc: int) -> None:

@@ -273,6 +273,7 @@ __device__ __forceinline__ float pde_residual(const PdeDev& p, const float* j, f
     }
     if constexpr (NT >= 1) {
       if (p.kind == PINN_PDE_ALLEN_CAHN) { d[0] = 3.0f * u * u - 1.0f; d[1] = 1.0f; return j[1] - u + u * u * u; }
+      if (p.kind == PINN_PDE_BLACK_SCHOLES) { d[0] = -p.c1; d[1] = 1.0f; return j[1] - p.c1 * u; }  // black_scholes.py:84-91: -rV survives
       d[1] = 1.0f;
       return j[1];
     }

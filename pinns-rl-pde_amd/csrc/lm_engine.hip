@@ -1,0 +1,757 @@
+// Host side of the layer-major engine: PinnNetDesc -> node program -> launch list (see lm_common.h).
+// tests/jet_model.py::net_program / program_forward / program_backward is the executable specification of this file.
+#include "lm_engine.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <vector>
+
+#include "lm_gemm.h"
+
+namespace pinn {
+namespace lm {
+
+namespace {
+
+__global__ void lm_pack_kernel(const PackTable tab, float* packed) {
+  const PackItem it = tab.item[blockIdx.y];
+  if (!it.src) return;
+  const int total = it.rows_p * it.cols_p;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / it.cols_p, c = i - r * it.cols_p;
+    float v = 0.0f;
+    if (it.transpose) {
+      if (c < it.rows && r < it.cols) v = it.src[c * it.cols + r];
+    } else {
+      if (r < it.rows && c < it.cols) v = it.src[r * it.cols + c];
+    }
+    packed[it.off + i] = v;
+  }
+}
+
+// user_grad += packed_grad (logical window only)
+__global__ void lm_unpack_kernel(const PackTable tab, const float* packed_grad) {
+  const PackItem it = tab.item[blockIdx.y];
+  if (!it.user_grad) return;
+  const int total = it.rows * it.cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / it.cols, c = i - r * it.cols;
+    const float g = it.transpose ? packed_grad[it.off + c * it.cols_p + r] : packed_grad[it.off + r * it.cols_p + c];
+    it.user_grad[i] += g;
+  }
+}
+
+int failf(char* err, size_t n, int code, const char* fmt, ...) {
+  if (err && n) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err, n, fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+int num_cus() {
+  static int cached = 0;
+  if (cached) return cached;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+      cus > 0) {
+    cached = cus;
+    return cus;
+  }
+  (void)hipGetLastError();
+  return 256;
+}
+
+// bytes of one record per chunk the sizing aims at (short-lived records of neighbouring launches then share the
+// 256 MB Infinity Cache); PINN_LM_RECORD_MB overrides it, read once
+size_t record_target_bytes() {
+  static size_t v = 0;
+  if (!v) {
+    const char* e = getenv("PINN_LM_RECORD_MB");
+    const long mb = e ? atol(e) : 0;
+    v = (size_t)(mb > 0 ? mb : 96) << 20;
+  }
+  return v;
+}
+
+float act_param_of(int act, float user) {
+  switch (act) {
+    case PINN_ACT_SIN: return user;
+    case PINN_ACT_RELU: return 0.0f;
+    case PINN_ACT_LEAKY_RELU: return 0.01f;
+    case PINN_ACT_IDENTITY: return 1.0f;
+    default: return 0.0f;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// program
+// ----------------------------------------------------------------------------------------------------------------
+struct Prologue {
+  int src_kind = SRC_REC;
+  int src_node = -1;   // SRC_REC: node whose Y record is the source
+  int enc_w = -1, enc_b = -1;  // tensor indices: first Linear (COORDS_LINEAR) or Fourier B (COORDS_FOURIER)
+  int ln_g = -1, ln_b = -1;    // tensor indices of the LayerNorm applied to the source
+  int skip_node = -1;  // node whose V record is added before the activation
+  int act = -1;        // PinnAct or -1
+  float act_param = 0.0f;
+  int H = 0;           // features of this prologue (= in-features of the GEMM that follows)
+  int M = 0;           // Fourier mapping size
+  bool identity() const { return src_kind == SRC_REC && ln_g < 0 && skip_node < 0 && act < 0; }
+};
+
+struct Node {
+  Prologue pro;
+  int w = -1, b = -1;  // tensor indices of the Linear
+  int Hin = 0, Hout = 0;
+  int add_node = -1;   // node whose V record is added to Y
+};
+
+struct Program {
+  int din = 0;
+  int n_nodes = 0;
+  Node node[kMaxNodes];
+  Prologue head;
+  int w_out = -1, b_out = -1;
+  int n_tensors = 0;
+  int rows[kMaxPack], cols[kMaxPack];  // logical shapes of the tensors the program uses (0 rows = unused)
+  bool transpose[kMaxPack];
+  bool enc_cols4[kMaxPack];            // (H x din) first-Linear weights are packed with 4 columns
+  float ln_eps = 1e-5f;
+};
+
+void use_tensor(Program& P, int idx, int rows, int cols, bool enc4 = false, bool transpose = false) {
+  P.rows[idx] = rows;
+  P.cols[idx] = cols;
+  P.enc_cols4[idx] = enc4;
+  P.transpose[idx] = transpose;
+}
+
+int expected_tensors(const PinnNetDesc* d) {
+  switch (d->arch) {
+    case PINN_ARCH_FOURIER: return 1 + 2 * d->num_linear;
+    case PINN_ARCH_FEEDFORWARD: return (d->flags & PINN_FLAG_LAYER_NORM) ? 4 * (d->num_linear - 1) + 2 : 2 * d->num_linear;
+    case PINN_ARCH_SIREN: return 2 * d->num_linear;
+    case PINN_ARCH_RESNET: return 4 + 8 * d->num_blocks;
+    case PINN_ARCH_ATTENTION: return 4 + 16 * d->num_blocks;
+    default: return -1;
+  }
+}
+
+int build_program(const PinnNetDesc* d, Program& P, char* err, size_t en) {
+  memset(&P, 0, sizeof(P));
+  for (int i = 0; i < kMaxPack; ++i) P.rows[i] = 0;
+  if (!d) return failf(err, en, PINN_ERR_BAD_DESC, "null descriptor");
+  if (d->num_linear < 2 || d->num_linear > PINN_MAX_LINEAR) return failf(err, en, PINN_ERR_BAD_DESC, "num_linear=%d outside [2,%d]", d->num_linear, PINN_MAX_LINEAR);
+  if (d->input_dim < 1 || d->input_dim > 4) return failf(err, en, PINN_ERR_UNSUPPORTED, "input_dim=%d (max 4)", d->input_dim);
+  if (d->widths[d->num_linear - 1] != 1) return failf(err, en, PINN_ERR_UNSUPPORTED, "output_dim must be 1");
+  if (d->activation < PINN_ACT_TANH || d->activation > PINN_ACT_IDENTITY) return failf(err, en, PINN_ERR_BAD_DESC, "unknown activation id %d", d->activation);
+  P.din = d->input_dim;
+  P.n_tensors = expected_tensors(d);
+  if (P.n_tensors < 0) return failf(err, en, PINN_ERR_UNSUPPORTED, "architecture id %d has no kernel", d->arch);
+  if (P.n_tensors > kMaxPack) return failf(err, en, PINN_ERR_UNSUPPORTED, "%d tensors exceed the pack table (%d)", P.n_tensors, kMaxPack);
+  P.ln_eps = d->ln_eps > 0.0f ? d->ln_eps : 1e-5f;
+  const int act = d->arch == PINN_ARCH_SIREN ? PINN_ACT_SIN : d->activation;
+  const float par = act_param_of(act, d->act_param);
+  auto check_w = [&](int wd) { return wd >= 1 && wd <= 1024; };
+  auto add_node = [&](const Prologue& pro, int w, int b, int Hin, int Hout, int add) -> int {
+    Node& nd = P.node[P.n_nodes];
+    nd.pro = pro;
+    nd.pro.H = Hin;
+    nd.w = w;
+    nd.b = b;
+    nd.Hin = Hin;
+    nd.Hout = Hout;
+    nd.add_node = add;
+    use_tensor(P, w, Hout, Hin);
+    use_tensor(P, b, 1, Hout);
+    return P.n_nodes++;
+  };
+  if (d->arch == PINN_ARCH_FOURIER) {
+    const int M = d->mapping_size;
+    if (M < 1 || 2 * M > 1024) return failf(err, en, PINN_ERR_UNSUPPORTED, "fourier mapping_size=%d", M);
+    use_tensor(P, 0, d->input_dim, M, false, true);
+    Prologue pro;
+    pro.src_kind = SRC_COORDS_FOURIER;
+    pro.enc_w = 0;
+    pro.M = M;
+    int prev = 2 * M;
+    for (int i = 0; i < d->num_linear - 1; ++i) {
+      const int wd = d->widths[i];
+      if (!check_w(wd)) return failf(err, en, PINN_ERR_UNSUPPORTED, "hidden width %d outside [1,1024]", wd);
+      if (P.n_nodes >= kMaxNodes) return failf(err, en, PINN_ERR_UNSUPPORTED, "too many layers");
+      const int m = add_node(pro, 1 + 2 * i, 2 + 2 * i, prev, wd, -1);
+      pro = Prologue();
+      pro.src_node = m;
+      pro.act = act;
+      pro.act_param = par;
+      prev = wd;
+    }
+    P.head = pro;
+    P.head.H = prev;
+    P.w_out = 1 + 2 * (d->num_linear - 1);
+    P.b_out = P.w_out + 1;
+  } else if (d->arch == PINN_ARCH_FEEDFORWARD || d->arch == PINN_ARCH_SIREN) {
+    const bool ln = d->arch == PINN_ARCH_FEEDFORWARD && (d->flags & PINN_FLAG_LAYER_NORM);
+    const int step = ln ? 4 : 2;
+    const int nh = d->num_linear - 1;  // hidden Linears
+    if (!check_w(d->widths[0])) return failf(err, en, PINN_ERR_UNSUPPORTED, "hidden width %d outside [1,1024]", d->widths[0]);
+    use_tensor(P, 0, d->widths[0], d->input_dim, true);
+    use_tensor(P, 1, 1, d->widths[0]);
+    Prologue pro;
+    pro.src_kind = SRC_COORDS_LINEAR;
+    pro.enc_w = 0;
+    pro.enc_b = 1;
+    pro.act = act;
+    pro.act_param = par;
+    if (ln) {
+      pro.ln_g = 2;
+      pro.ln_b = 3;
+      use_tensor(P, 2, 1, d->widths[0]);
+      use_tensor(P, 3, 1, d->widths[0]);
+    }
+    int prev = d->widths[0];
+    for (int i = 1; i < nh; ++i) {
+      const int wd = d->widths[i];
+      if (!check_w(wd)) return failf(err, en, PINN_ERR_UNSUPPORTED, "hidden width %d outside [1,1024]", wd);
+      if (P.n_nodes >= kMaxNodes) return failf(err, en, PINN_ERR_UNSUPPORTED, "too many layers");
+      const int m = add_node(pro, step * i, step * i + 1, prev, wd, -1);
+      pro = Prologue();
+      pro.src_node = m;
+      pro.act = act;
+      pro.act_param = par;
+      if (ln) {
+        pro.ln_g = step * i + 2;
+        pro.ln_b = step * i + 3;
+        use_tensor(P, pro.ln_g, 1, wd);
+        use_tensor(P, pro.ln_b, 1, wd);
+      }
+      prev = wd;
+    }
+    P.head = pro;
+    P.head.H = prev;
+    P.w_out = step * nh;
+    P.b_out = P.w_out + 1;
+  } else if (d->arch == PINN_ARCH_RESNET) {
+    const int nb = d->num_blocks, H = d->widths[0];
+    if (nb < 1 || 2 * nb > kMaxNodes || d->num_linear != 2 * nb + 2) return failf(err, en, PINN_ERR_BAD_DESC, "resnet: num_blocks=%d / num_linear=%d", nb, d->num_linear);
+    if (!check_w(H)) return failf(err, en, PINN_ERR_UNSUPPORTED, "resnet width %d outside [1,1024]", H);
+    use_tensor(P, 0, H, d->input_dim, true);
+    use_tensor(P, 1, 1, H);
+    Prologue pro;
+    pro.src_kind = SRC_COORDS_LINEAR;
+    pro.enc_w = 0;
+    pro.enc_b = 1;
+    pro.act = act;
+    pro.act_param = par;
+    for (int b = 0; b < nb; ++b) {
+      const int base = 2 + 8 * b;
+      const int n1 = add_node(pro, base, base + 1, H, H, -1);
+      Prologue p2;
+      p2.src_node = n1;
+      p2.ln_g = base + 2;
+      p2.ln_b = base + 3;
+      p2.act = act;
+      p2.act_param = par;
+      use_tensor(P, base + 2, 1, H);
+      use_tensor(P, base + 3, 1, H);
+      const int n2 = add_node(p2, base + 4, base + 5, H, H, -1);
+      pro = Prologue();  // q_b = LN2(z2_b) + V(n1_b);  h_b = act(q_b)
+      pro.src_node = n2;
+      pro.ln_g = base + 6;
+      pro.ln_b = base + 7;
+      pro.skip_node = n1;
+      pro.act = act;
+      pro.act_param = par;
+      use_tensor(P, base + 6, 1, H);
+      use_tensor(P, base + 7, 1, H);
+    }
+    P.head = pro;
+    P.head.H = H;
+    P.w_out = 2 + 8 * nb;
+    P.b_out = P.w_out + 1;
+  } else if (d->arch == PINN_ARCH_ATTENTION) {
+    const int nl = d->num_blocks, H = d->widths[0];
+    if (nl < 1 || 4 * nl > kMaxNodes || d->num_linear != 2) return failf(err, en, PINN_ERR_BAD_DESC, "attention: num_blocks=%d / num_linear=%d", nl, d->num_linear);
+    if (!check_w(H) || 4 * H > 1024) return failf(err, en, PINN_ERR_UNSUPPORTED, "attention width %d outside [1,256]", H);
+    use_tensor(P, 0, H, d->input_dim, true);
+    use_tensor(P, 1, 1, H);
+    Prologue pro;
+    pro.src_kind = SRC_COORDS_LINEAR;
+    pro.enc_w = 0;
+    pro.enc_b = 1;
+    pro.act = act;
+    pro.act_param = par;
+    for (int l = 0; l < nl; ++l) {
+      const int base = 2 + 16 * l;  // q(0,1) k(2,3) value(4,5) proj(6,7) LN_a(8,9) net.0(10,11) net.3(12,13) LN_f(14,15)
+      const int nv = add_node(pro, base + 4, base + 5, H, H, -1);
+      Prologue pid;  // identity: the projection consumes the value record as it stands
+      pid.src_node = nv;
+      const int np = add_node(pid, base + 6, base + 7, H, H, nv);  // za = W_p v + b_p + h
+      Prologue p1;
+      p1.src_node = np;
+      p1.ln_g = base + 8;
+      p1.ln_b = base + 9;
+      use_tensor(P, base + 8, 1, H);
+      use_tensor(P, base + 9, 1, H);
+      const int n1 = add_node(p1, base + 10, base + 11, H, 4 * H, -1);
+      Prologue p2;
+      p2.src_node = n1;
+      p2.act = PINN_ACT_GELU;
+      const int n2 = add_node(p2, base + 12, base + 13, 4 * H, H, n1);  // zf = W_2 gelu(z1) + b_2 + h1
+      pro = Prologue();
+      pro.src_node = n2;
+      pro.ln_g = base + 14;
+      pro.ln_b = base + 15;
+      use_tensor(P, base + 14, 1, H);
+      use_tensor(P, base + 15, 1, H);
+    }
+    P.head = pro;
+    P.head.H = H;
+    P.w_out = 2 + 16 * nl;
+    P.b_out = P.w_out + 1;
+  } else {
+    return failf(err, en, PINN_ERR_UNSUPPORTED, "architecture id %d has no kernel", d->arch);
+  }
+  use_tensor(P, P.w_out, 1, P.head.H);
+  use_tensor(P, P.b_out, 1, 1);
+  return PINN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// workspace layout
+// ----------------------------------------------------------------------------------------------------------------
+struct Layout {
+  PackTable tab;
+  size_t n_packed = 0;       // floats of one packed block (parameters; gradients have the same layout)
+  long long ct = 0;          // tiles per chunk
+  int K = 0;
+  // offsets in floats from the workspace start
+  size_t params = 0, grads = 0, U = 0;
+  size_t V[kMaxNodes], Y[kMaxNodes], Vh = 0;
+  size_t Zbar[kMaxNodes], Vbar[kMaxNodes], Pbar[kMaxNodes + 1];  // Pbar[m]: skip cotangent produced by node m's prologue (kMaxNodes = head)
+  size_t partial = 0, partial_floats = 0;
+  size_t total = 0;          // floats
+};
+
+size_t rec_floats(long long ct, int K, int H) { return (size_t)ct * K * round32(H) * kT; }
+
+void make_layout(const Program& P, long long N, int K, bool bwd, bool deterministic, Layout& L) {
+  memset(&L.tab, 0, sizeof(L.tab));
+  L.K = K;
+  size_t off = 0;
+  L.tab.n = P.n_tensors;
+  for (int i = 0; i < P.n_tensors; ++i) {
+    PackItem& it = L.tab.item[i];
+    it.src = nullptr;
+    it.user_grad = nullptr;
+    it.off = (unsigned)off;
+    it.rows = P.rows[i];
+    it.cols = P.cols[i];
+    it.transpose = P.transpose[i] ? 1 : 0;
+    if (P.rows[i] == 0) continue;
+    if (P.transpose[i]) {  // Fourier B (din x M) -> [round32(M)][4]
+      it.rows_p = round32(P.cols[i]);
+      it.cols_p = 4;
+    } else if (P.enc_cols4[i]) {  // first Linear (H x din) -> [round32(H)][4]
+      it.rows_p = round32(P.rows[i]);
+      it.cols_p = 4;
+    } else {
+      it.rows_p = P.rows[i] == 1 ? 1 : round32(P.rows[i]);
+      it.cols_p = round32(P.cols[i]);
+    }
+    off += (size_t)it.rows_p * it.cols_p;
+  }
+  L.n_packed = off;
+  // chunk size: the widest record of a chunk stays near the target
+  int hmax = P.head.H;
+  for (int m = 0; m < P.n_nodes; ++m) {
+    if (P.node[m].Hin > hmax) hmax = P.node[m].Hin;
+    if (P.node[m].Hout > hmax) hmax = P.node[m].Hout;
+  }
+  const long long ntiles = (N + kT - 1) / kT;
+  long long ct = (long long)(record_target_bytes() / ((size_t)K * round32(hmax) * kT * sizeof(float)));
+  if (ct < 64) ct = 64;
+  if (ct > ntiles) ct = ntiles;
+  L.ct = ct;
+  size_t o = 0;
+  L.params = o;
+  o += L.n_packed;
+  L.grads = o;
+  if (bwd) o += L.n_packed;
+  L.U = o;
+  o += (size_t)ct * K * kT;
+  for (int m = 0; m < P.n_nodes; ++m) {
+    const Node& nd = P.node[m];
+    if (nd.pro.identity()) {
+      L.V[m] = L.Y[nd.pro.src_node];
+    } else {
+      L.V[m] = o;
+      o += rec_floats(ct, K, nd.Hin);
+    }
+    L.Y[m] = o;
+    o += rec_floats(ct, K, nd.Hout);
+  }
+  L.Vh = o;
+  o += rec_floats(ct, K, P.head.H);
+  if (bwd) {
+    for (int m = 0; m < P.n_nodes; ++m) {
+      L.Zbar[m] = o;
+      o += rec_floats(ct, K, P.node[m].Hout);
+    }
+    for (int m = 0; m < P.n_nodes; ++m) {
+      const Node& nd = P.node[m];
+      if (nd.pro.identity()) {
+        L.Vbar[m] = L.Zbar[nd.pro.src_node];  // the cotangent of V IS the cotangent of the source record
+      } else {
+        L.Vbar[m] = o;
+        o += rec_floats(ct, K, nd.Hin);
+      }
+      L.Pbar[m] = 0;
+      if (nd.pro.skip_node >= 0) {
+        L.Pbar[m] = o;
+        o += rec_floats(ct, K, nd.Hin);
+      }
+    }
+    L.Pbar[kMaxNodes] = 0;
+    if (P.head.skip_node >= 0) {
+      L.Pbar[kMaxNodes] = o;
+      o += rec_floats(ct, K, P.head.H);
+    }
+    L.partial = o;
+    L.partial_floats = 0;
+    if (deterministic) {
+      size_t big = 0;
+      for (int m = 0; m < P.n_nodes; ++m) {
+        const size_t e = (size_t)round32(P.node[m].Hout) * round32(P.node[m].Hin) + round32(P.node[m].Hout);
+        if (e > big) big = e;
+      }
+      L.partial_floats = big * 512;  // up to 512 splits per weight-gradient launch
+      o += L.partial_floats;
+    }
+  }
+  L.total = o;
+}
+
+int fpt_for(int Hp) { return Hp <= 64 ? 1 : (Hp <= 256 ? 4 : (Hp <= 512 ? 8 : 16)); }
+
+hipError_t allow_lds(const void* kern, size_t bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> guard(mu);
+  if (done.count({kern, dev})) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) done.insert({kern, dev});
+  (void)bytes;
+  return e;
+}
+
+hipError_t launch_ew(int nt, int nx, const EwArgs& a, bool bwd, int act, int fpt, int grid, hipStream_t st) {
+#define PINN_LM_CASE(NT_, NX_) \
+  if (nt == NT_ && nx == NX_) return launch_lm_ew_##NT_##_##NX_(a, bwd, act, fpt, grid, st);
+  PINN_LM_CASE(0, 0) PINN_LM_CASE(1, 0) PINN_LM_CASE(1, 1) PINN_LM_CASE(1, 2) PINN_LM_CASE(1, 3) PINN_LM_CASE(1, 4)
+  PINN_LM_CASE(2, 0) PINN_LM_CASE(2, 2)
+#undef PINN_LM_CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_head(int nt, int nx, const HeadArgs& a, int fpt, int grid, hipStream_t st) {
+#define PINN_LM_CASE(NT_, NX_) \
+  if (nt == NT_ && nx == NX_) return launch_lm_head_##NT_##_##NX_(a, fpt, grid, st);
+  PINN_LM_CASE(0, 0) PINN_LM_CASE(1, 0) PINN_LM_CASE(1, 1) PINN_LM_CASE(1, 2) PINN_LM_CASE(1, 3) PINN_LM_CASE(1, 4)
+  PINN_LM_CASE(2, 0) PINN_LM_CASE(2, 2)
+#undef PINN_LM_CASE
+  return hipErrorInvalidValue;
+}
+
+template <bool COLS>
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
+  const int out_rows = COLS ? g.w_cols : g.w_rows;
+  const int depth = COLS ? g.w_rows : g.w_cols;
+  const int items = (g.ncb + kCB - 1) / kCB;
+  const size_t lds = lm_gemm_lds_bytes(depth);
+  hipError_t e;
+  if (out_rows > 128) {
+    auto kern = lm_gemm<COLS, 2>;
+    if ((e = allow_lds(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return e;
+    const int gy = (out_rows + 255) / 256;
+    int gx = 2 * num_cus() / gy;
+    if (gx < 1) gx = 1;
+    if (gx > items) gx = items;
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(kThreads), lds, st, g);
+  } else {
+    auto kern = lm_gemm<COLS, 1>;
+    if ((e = allow_lds(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return e;
+    int gx = 2 * num_cus();
+    if (gx > items) gx = items;
+    hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kThreads), lds, st, g);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+int lm_expected_tensors(const PinnNetDesc* d) { return d ? expected_tensors(d) : -1; }
+
+int lm_check(const PinnNetDesc* d, char* err, size_t errlen) {
+  Program P;
+  return build_program(d, P, err, errlen);
+}
+
+size_t lm_workspace_bytes(const PinnNetDesc* d, long long N, int nt, int nx, bool bwd, bool deterministic) {
+  if (N <= 0) return 0;
+  Program P;
+  char err[64];
+  if (build_program(d, P, err, sizeof(err)) != PINN_OK) return 0;
+  Layout L;
+  make_layout(P, N, 1 + nt + nx, bwd, deterministic, L);
+  return (L.total * sizeof(float) + 255) & ~(size_t)255;
+}
+
+int lm_run(const CallArgs& c, char* err, size_t en) {
+  Program P;
+  int rc = build_program(c.net, P, err, en);
+  if (rc) return rc;
+  if (c.num_tensors != P.n_tensors)
+    return failf(err, en, PINN_ERR_BAD_DESC, "weight table has %d entries, this architecture's state_dict has %d", c.num_tensors, P.n_tensors);
+  const int K = 1 + c.nt + c.nx;
+  static thread_local Layout L;  // 10 KB of offsets: keep it off the stack
+  make_layout(P, c.N, K, c.bwd, c.deterministic, L);
+  const size_t need = (L.total * sizeof(float) + 255) & ~(size_t)255;
+  if (!c.workspace || c.ws_bytes < need) return failf(err, en, PINN_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, c.ws_bytes);
+  if (reinterpret_cast<uintptr_t>(c.workspace) & 15) return failf(err, en, PINN_ERR_MISALIGNED, "workspace is not 16-byte aligned");
+  float* ws = static_cast<float*>(c.workspace);
+  hipStream_t st = c.stream;
+  hipError_t e = hipSuccess;
+#define LM_CHECK(call)                                                                                     \
+  do {                                                                                                     \
+    e = (call);                                                                                            \
+    if (e != hipSuccess) return failf(err, en, PINN_ERR_HIP, "HIP error %d: %s (%s)", (int)e, hipGetErrorString(e), #call); \
+  } while (0)
+
+  // ---- pack parameters (and zero the packed gradients) ----
+  for (int i = 0; i < P.n_tensors; ++i) {
+    if (P.rows[i] == 0) continue;
+    if (!c.weights[i]) return failf(err, en, PINN_ERR_BAD_DESC, "weight pointer %d is null", i);
+    L.tab.item[i].src = c.weights[i];
+    L.tab.item[i].user_grad = (c.bwd && c.grads && !P.transpose[i]) ? c.grads[i] : nullptr;
+  }
+  float* params = ws + L.params;
+  float* grads = ws + L.grads;
+  hipLaunchKernelGGL(lm_pack_kernel, dim3(8, P.n_tensors), dim3(256), 0, st, L.tab, params);
+  LM_CHECK(hipGetLastError());
+  if (c.bwd) LM_CHECK(hipMemsetAsync(grads, 0, L.n_packed * sizeof(float), st));
+  auto pp = [&](int idx) -> const float* { return idx >= 0 ? params + L.tab.item[idx].off : nullptr; };
+  auto gp = [&](int idx) -> float* { return (idx >= 0 && c.bwd && c.grads && c.grads[idx]) ? grads + L.tab.item[idx].off : nullptr; };
+
+  const long long ntiles = (c.N + kT - 1) / kT;
+  const int cus = num_cus();
+
+  auto fill_ew = [&](EwArgs& a, const Prologue& pro, long long ct, long long p_base) {
+    memset(&a, 0, sizeof(a));
+    a.H = pro.H;
+    a.Hp = round32(pro.H);
+    const int fpt = fpt_for(a.Hp);
+    a.G = a.Hp / fpt;
+    a.ntiles = ct;
+    a.N = c.N;
+    a.p_base = p_base;
+    a.src_kind = pro.src_kind;
+    a.din = P.din;
+    a.M = pro.M;
+    a.x = c.x;
+    a.t = c.t;
+    a.eps = P.ln_eps;
+    a.has_act = pro.act >= 0;
+    a.act_param = pro.act_param;
+    if (pro.src_kind == SRC_REC) a.srcA = ws + L.Y[pro.src_node];
+    else {
+      a.encW = pp(pro.enc_w);
+      a.encb = pp(pro.enc_b);
+    }
+    a.ln_g = pp(pro.ln_g);
+    a.ln_b = pp(pro.ln_b);
+    a.skip = pro.skip_node >= 0 ? ws + L.V[pro.skip_node] : nullptr;
+    return fpt;
+  };
+  auto ew_grid = [&](long long ct) {
+    long long g = 2LL * ct;
+    const long long cap = 2LL * cus;
+    return (int)(g < cap ? g : cap);
+  };
+
+  for (long long t0 = 0; t0 < ntiles; t0 += L.ct) {
+    const long long ct = ntiles - t0 < L.ct ? ntiles - t0 : L.ct;
+    const long long p_base = t0 * kT;
+    const int ncb = (int)(ct * K);
+    // ---------------- forward ----------------
+    for (int m = 0; m < P.n_nodes; ++m) {
+      const Node& nd = P.node[m];
+      if (!nd.pro.identity()) {
+        EwArgs a;
+        const int fpt = fill_ew(a, nd.pro, ct, p_base);
+        a.V = ws + L.V[m];
+        if (nd.pro.src_kind == SRC_COORDS_FOURIER) LM_CHECK(launch_ew(c.nt, c.nx, a, false, -2, fpt, ew_grid(ct), st));
+        else LM_CHECK(launch_ew(c.nt, c.nx, a, false, nd.pro.act, fpt, ew_grid(ct), st));
+      }
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.W = pp(nd.w);
+      g.bias = pp(nd.b);
+      g.X = ws + L.V[m];
+      g.Y = ws + L.Y[m];
+      g.add0 = nd.add_node >= 0 ? ws + L.V[nd.add_node] : nullptr;
+      g.w_rows = round32(nd.Hout);
+      g.w_cols = round32(nd.Hin);
+      g.ncb = ncb;
+      g.K = K;
+      LM_CHECK(launch_gemm<false>(g, st));
+    }
+    {
+      EwArgs a;
+      const int fpt = fill_ew(a, P.head, ct, p_base);
+      a.V = ws + L.Vh;
+      if (P.head.src_kind == SRC_COORDS_FOURIER) LM_CHECK(launch_ew(c.nt, c.nx, a, false, -2, fpt, ew_grid(ct), st));
+      else LM_CHECK(launch_ew(c.nt, c.nx, a, false, P.head.act, fpt, ew_grid(ct), st));
+      HeadArgs h;
+      memset(&h, 0, sizeof(h));
+      h.H = a.H;
+      h.Hp = a.Hp;
+      h.G = a.G;
+      h.ntiles = ct;
+      h.N = c.N;
+      h.p_base = p_base;
+      h.V = ws + L.Vh;
+      h.w_out = pp(P.w_out);
+      h.b_out = c.weights[P.b_out];
+      h.pde = c.pde;
+      h.mode = c.mode;
+      h.bwd = c.bwd ? 1 : 0;
+      h.grad_scale = c.grad_scale;
+      h.x = c.x;
+      h.din = P.din;
+      for (int s = 0; s < K; ++s) {
+        h.jets_out[s] = c.jets_out ? c.jets_out[s] : nullptr;
+        h.jets_bar[s] = c.jets_bar ? c.jets_bar[s] : nullptr;
+      }
+      h.residual_out = c.residual_out;
+      h.loss_sum = c.loss_sum;
+      h.res_bar = c.res_bar;
+      h.U = ws + L.U;
+      h.dw_out = gp(P.w_out);
+      h.db_out = gp(P.b_out);
+      LM_CHECK(launch_head(c.nt, c.nx, h, fpt, ew_grid(ct), st));
+    }
+    if (!c.bwd) continue;
+    // ---------------- reverse ----------------
+    // extra cotangents of V records: skip connections (Pbar of the consumer's prologue) and epilogue adds (Zbar of the adding node)
+    const float* extra[kMaxNodes][2];
+    for (int m = 0; m < P.n_nodes; ++m) extra[m][0] = extra[m][1] = nullptr;
+    auto add_extra = [&](int m, const float* rec) {
+      if (!extra[m][0]) extra[m][0] = rec;
+      else extra[m][1] = rec;
+    };
+    auto run_ew_bwd = [&](const Prologue& pro, int self, const float* vbar) -> int {
+      // self = node index (kMaxNodes for the head); vbar = cotangent record of its V, or null for the head's (U, w_out) form
+      const bool needs = pro.src_kind == SRC_REC || (pro.src_kind == SRC_COORDS_LINEAR) || pro.ln_g >= 0 || pro.skip_node >= 0;
+      if (!needs) return PINN_OK;  // Fourier features straight from the coordinates: nothing upstream to differentiate
+      EwArgs a;
+      const int fpt = fill_ew(a, pro, ct, p_base);
+      a.Vbar = vbar;
+      if (!vbar) {
+        a.U = ws + L.U;
+        a.w_out = pp(P.w_out);
+      }
+      if (pro.src_kind == SRC_REC) a.Zbar = ws + L.Zbar[pro.src_node];
+      if (pro.skip_node >= 0) {
+        a.Pbar = ws + L.Pbar[self];
+        add_extra(pro.skip_node, a.Pbar);
+      }
+      a.d_ln_g = gp(pro.ln_g);
+      a.d_ln_b = gp(pro.ln_b);
+      if (pro.src_kind == SRC_COORDS_LINEAR) {
+        a.d_encW = gp(pro.enc_w);
+        a.d_encb = gp(pro.enc_b);
+        if (!a.d_encW && pro.ln_g < 0 && pro.skip_node < 0) return PINN_OK;
+      }
+      e = launch_ew(c.nt, c.nx, a, true, pro.act, fpt, ew_grid(ct), st);
+      if (e != hipSuccess) return failf(err, en, PINN_ERR_HIP, "HIP error %d: %s (lm_ew_bwd)", (int)e, hipGetErrorString(e));
+      return PINN_OK;
+    };
+    if ((rc = run_ew_bwd(P.head, kMaxNodes, nullptr)) != PINN_OK) return rc;
+    for (int m = P.n_nodes - 1; m >= 0; --m) {
+      const Node& nd = P.node[m];
+      const float* zbar = ws + L.Zbar[m];
+      if (nd.add_node >= 0) add_extra(nd.add_node, zbar);
+      // weight gradient
+      if (gp(nd.w) || gp(nd.b)) {
+        GemmNtArgs g;
+        memset(&g, 0, sizeof(g));
+        g.Z = zbar;
+        g.V = ws + L.V[m];
+        g.dW = grads + L.tab.item[nd.w].off;
+        g.db = gp(nd.b);
+        g.z_rows = round32(nd.Hout);
+        g.v_rows = round32(nd.Hin);
+        g.ncb = ncb;
+        g.K = K;
+        const int gy = (g.z_rows + 127) / 128, gz = (g.v_rows + kNtCols - 1) / kNtCols;
+        int gx = 2 * cus / (gy * gz);
+        if (gx < 1) gx = 1;
+        if (gx > ncb) gx = ncb;
+        if (gx > 512) gx = 512;
+        const size_t lds = lm_gemm_nt_lds_bytes();
+        LM_CHECK(allow_lds(reinterpret_cast<const void*>(lm_gemm_nt), lds));
+        if (c.deterministic) {
+          g.partial = ws + L.partial;
+          // every element of a split's partial block is stored by exactly one workgroup (blockIdx.y, blockIdx.z)
+          const size_t stride = (size_t)g.z_rows * g.v_rows + g.z_rows;
+          hipLaunchKernelGGL(lm_gemm_nt, dim3(gx, gy, gz), dim3(kThreads), lds, st, g);
+          LM_CHECK(hipGetLastError());
+          hipLaunchKernelGGL(lm_reduce_partials, dim3(256), dim3(256), 0, st, g.partial, (long long)stride, gx, g.dW,
+                             (long long)g.z_rows * g.v_rows, g.db, g.z_rows);
+          LM_CHECK(hipGetLastError());
+        } else {
+          hipLaunchKernelGGL(lm_gemm_nt, dim3(gx, gy, gz), dim3(kThreads), lds, st, g);
+          LM_CHECK(hipGetLastError());
+        }
+      }
+      // cotangent of this node's GEMM input, then through its prologue
+      const Prologue& pro = nd.pro;
+      const bool upstream = pro.src_kind == SRC_REC || pro.src_kind == SRC_COORDS_LINEAR || pro.ln_g >= 0 || pro.skip_node >= 0;
+      if (!upstream) continue;
+      if (pro.src_kind == SRC_COORDS_LINEAR && !gp(pro.enc_w) && !gp(pro.enc_b) && pro.ln_g < 0 && pro.skip_node < 0) continue;
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.W = pp(nd.w);
+      g.X = zbar;
+      g.Y = ws + L.Vbar[m];
+      g.add0 = extra[m][0];
+      g.add1 = extra[m][1];
+      g.w_rows = round32(nd.Hout);
+      g.w_cols = round32(nd.Hin);
+      g.ncb = ncb;
+      g.K = K;
+      LM_CHECK(launch_gemm<true>(g, st));
+      if (!pro.identity() && (rc = run_ew_bwd(pro, m, ws + L.Vbar[m])) != PINN_OK) return rc;
+    }
+  }
+  if (c.bwd) {
+    hipLaunchKernelGGL(lm_unpack_kernel, dim3(8, P.n_tensors), dim3(256), 0, st, L.tab, grads);
+    LM_CHECK(hipGetLastError());
+  }
+#undef LM_CHECK
+  return PINN_OK;
+}
+
+}  // namespace lm
+}  // namespace pinn

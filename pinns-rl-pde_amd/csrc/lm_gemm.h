@@ -1,0 +1,334 @@
+// Dense fp32 MFMA GEMMs of the layer-major engine (see lm_common.h).  gfx950, v_mfma_f32_32x32x2_f32.
+//
+// The operands are plain matrices: a packed zero-padded weight (rows x cols, both multiples of 32) and records whose
+// column blocks are (rows_p x 32) slabs.  Nothing here knows about jets — a stream is just more columns.
+//
+//   lm_gemm<COLS=false>   Y[cb] = W  X[cb] (+ bias on value-stream blocks) (+ add records)      "rows" form
+//   lm_gemm<COLS=true>    Y[cb] = W^T X[cb] (+ add records)                                      "cols" form
+//   lm_gemm_nt            dW += sum_cb Z[cb] V[cb]^T ,  db += sum over value-stream blocks of Z[cb] 1
+//
+// lm_gemm: a 256-thread workgroup stages CB = 2 column blocks of the input (up to 256 reduction rows, 72 KB of LDS:
+// two workgroups per CU overlap each other's staging / store phases with MFMA), every wave owns 32-row output tiles,
+// the weight operand streams from L2 one 32-deep chunk ahead of its MFMAs (rows form: 16-byte loads along k; cols
+// form: 128-byte coalesced dword loads of weight columns, no transposed copy), the B operand is read from LDS one
+// k-group ahead (sched_barrier-pinned, see jet_kernel_wide.h for why).
+// lm_gemm_nt: a workgroup accumulates a 128 x (<= 256) block of dW in registers over ALL column blocks of its
+// split (128 accumulator registers per lane) and flushes once: no atomics inside the loop.
+#pragma once
+#include "lm_common.h"
+
+namespace pinn {
+namespace lm {
+
+constexpr int kCB = 2;     // column blocks per staged image
+constexpr int kKC = 256;   // reduction rows per staged chunk
+
+struct GemmArgs {
+  const float* W;     // packed weight, (w_rows x w_cols), row stride w_cols
+  const float* bias;  // rows form: w_rows floats or null
+  const float* X;     // input record: ncb blocks of (x_rows x 32)
+  float* Y;           // output record: ncb blocks of (y_rows x 32)
+  const float* add0;  // optional records added to Y (shape of Y)
+  const float* add1;
+  int w_rows, w_cols;
+  int ncb;            // column blocks = tiles * K
+  int K;              // streams per tile: bias goes to blocks with cb % K == 0
+};
+
+struct WFrag16 {
+  f32x4 g[4];
+};
+
+__device__ __forceinline__ void ld_rows(WFrag16& w, const float* W, unsigned lane_off, int ch) {
+  const char* base = reinterpret_cast<const char*>(W + 32 * ch);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) w.g[g] = *reinterpret_cast<const f32x4*>(base + lane_off + 32u * g);
+}
+
+__device__ __forceinline__ void ld_cols(WFrag16& w, const float* W, int ld, unsigned lane_off, int ch) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* base = reinterpret_cast<const char*>(W + (long long)(32 * ch + 8 * g + i) * ld);
+      w.g[g][i] = *reinterpret_cast<const float*>(base + lane_off);
+    }
+}
+
+// acc[c] += Wslice(32 x 32 nc) . img[c][0 .. 32 nc)[n]      img: [kCB][kc_rows][kTP]
+template <bool COLS>
+__device__ __forceinline__ void gemm_core(f32x16 (&acc)[kCB], const float* W, int ld, unsigned lane_off, int nc,
+                                          const float* img, int kc_rows, const Lane& L) {
+  const float* col = img + (4 * L.lh) * kTP + L.ln;
+  float bc[4][kCB], bn[4][kCB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < kCB; ++c) bc[i][c] = col[(c * kc_rows + i) * kTP];
+  WFrag16 cur, nxt;
+  if constexpr (COLS) ld_cols(cur, W, ld, lane_off, 0);
+  else ld_rows(cur, W, lane_off, 0);
+#pragma unroll 1
+  for (int ch = 0; ch < nc; ++ch) {
+    const int chn = ch + 1 < nc ? ch + 1 : ch;  // the last chunk re-requests itself (branch-free, harmless)
+    if constexpr (COLS) ld_cols(nxt, W, ld, lane_off, chn);
+    else ld_rows(nxt, W, lane_off, chn);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int kn = 32 * ch + 8 * (g + 1);
+      if (kn >= 32 * nc) kn = 32 * ch + 8 * g;  // last group of the last chunk: re-read its own rows
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) bn[i][c] = col[(c * kc_rows + kn + i) * kTP];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.g[g][i], bc[i][c], acc[c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) bc[i][c] = bn[i][c];
+    }
+    cur = nxt;
+  }
+}
+
+// NTILE: 32-row output tiles per wave (1: 128-row workgroup blocks, 2: 256-row blocks)
+template <bool COLS, int NTILE>
+__global__ __launch_bounds__(kThreads, 2) void lm_gemm(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  Lane L;
+  L.tid = threadIdx.x;
+  L.wave = __builtin_amdgcn_readfirstlane(L.tid >> 6);
+  L.ln = L.tid & 31;
+  L.lh = (L.tid >> 5) & 1;
+  const int out_rows = COLS ? a.w_cols : a.w_rows;
+  const int depth = COLS ? a.w_rows : a.w_cols;
+  const int x_rows = depth, y_rows = out_rows;
+  const int row_blk = blockIdx.y * (128 * NTILE);
+  const int items = (a.ncb + kCB - 1) / kCB;
+  const int kc_rows = depth < kKC ? depth : kKC;
+
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int cb0 = item * kCB;
+    f32x16 acc[NTILE][kCB];
+#pragma unroll
+    for (int jt = 0; jt < NTILE; ++jt)
+#pragma unroll
+      for (int c = 0; c < kCB; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][c][r] = 0.0f;
+    for (int k0 = 0; k0 < depth; k0 += kKC) {
+      const int kn = depth - k0 < kKC ? depth - k0 : kKC;  // rows of this chunk (multiple of 32)
+      __syncthreads();  // readers of the previous image are done
+      // stage X[cb0 .. cb0+CB)[k0 .. k0+kn)[32] -> img[c][r][kTP]; 8 float4 per row
+      {
+        const int quads = kn * 8;
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) {
+          const bool ok = cb0 + c < a.ncb;
+          const float* src = a.X + ((long long)(cb0 + c) * x_rows + k0) * kT;
+          for (int q0 = 0; q0 < quads; q0 += 4 * kThreads) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int q = q0 + u * kThreads + L.tid;
+              v[u] = (ok && q < quads) ? *reinterpret_cast<const f32x4*>(src + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int q = q0 + u * kThreads + L.tid;
+              if (q < quads) *reinterpret_cast<f32x4*>(smem + (c * kc_rows + (q >> 3)) * kTP + 4 * (q & 7)) = v[u];
+            }
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int jt = 0; jt < NTILE; ++jt) {
+        const int row0 = row_blk + (L.wave + kWaves * jt) * 32;
+        if (row0 < out_rows) {
+          if constexpr (COLS) {
+            const unsigned lane_off = static_cast<unsigned>(4 * L.lh * a.w_cols + row0 + L.ln) * 4u;
+            gemm_core<true>(acc[jt], a.W + (long long)k0 * a.w_cols, a.w_cols, lane_off, kn >> 5, smem, kc_rows, L);
+          } else {
+            const unsigned lane_off = static_cast<unsigned>((row0 + L.ln) * a.w_cols + 4 * L.lh) * 4u;
+            gemm_core<false>(acc[jt], a.W + k0, a.w_cols, lane_off, kn >> 5, smem, kc_rows, L);
+          }
+        }
+      }
+    }
+    // epilogue: bias on value-stream blocks, optional adds, 128-byte row segments per half wave
+#pragma unroll
+    for (int jt = 0; jt < NTILE; ++jt) {
+      const int row0 = row_blk + (L.wave + kWaves * jt) * 32;
+      if (row0 >= out_rows) continue;
+#pragma unroll
+      for (int c = 0; c < kCB; ++c) {
+        const int cb = cb0 + c;
+        if (cb >= a.ncb) continue;
+        const bool with_bias = !COLS && a.bias && (cb % a.K) == 0;
+        const long long base = ((long long)cb * y_rows + row0) * kT + L.ln;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = acc_row(r, L.lh);
+          float v = acc[jt][c][r];
+          if (with_bias) v += a.bias[row0 + rr];
+          if (a.add0) v += a.add0[base + rr * kT];
+          if (a.add1) v += a.add1[base + rr * kT];
+          a.Y[base + rr * kT] = v;
+        }
+      }
+    }
+  }
+}
+
+inline size_t lm_gemm_lds_bytes(int depth) { return sizeof(float) * (size_t)kCB * (depth < kKC ? depth : kKC) * kTP; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------------
+struct GemmNtArgs {
+  const float* Z;   // cotangent record: ncb blocks of (z_rows x 32)        z_rows = out features (padded)
+  const float* V;   // GEMM-input record: ncb blocks of (v_rows x 32)       v_rows = in features (padded)
+  float* dW;        // packed gradient (z_rows x v_rows), accumulated with float atomics at the end
+  float* db;        // packed (z_rows) or null
+  float* partial;   // deterministic mode: per-split partial blocks [(split)][z_rows x v_rows (+ z_rows)] or null
+  int z_rows, v_rows;
+  int ncb, K;
+};
+
+constexpr int kNtCols = 128;  // dW columns per workgroup (64 accumulator registers per lane)
+
+template <int NA>
+__device__ __forceinline__ void outer_block(f32x16 (&dacc)[kNtCols / 32], const float* zrow, const float* arow) {
+  f32x4 zc, zn, ac[NA], an[NA];
+  zc = *reinterpret_cast<const f32x4*>(zrow);
+#pragma unroll
+  for (int kt = 0; kt < NA; ++kt) ac[kt] = *reinterpret_cast<const f32x4*>(arow + kt * 32 * kTP);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g + 1 < 4) {
+      zn = *reinterpret_cast<const f32x4*>(zrow + 8 * (g + 1));
+#pragma unroll
+      for (int kt = 0; kt < NA; ++kt) an[kt] = *reinterpret_cast<const f32x4*>(arow + kt * 32 * kTP + 8 * (g + 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kt = 0; kt < NA; ++kt) dacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zc[i], ac[kt][i], dacc[kt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < 4) {
+      zc = zn;
+#pragma unroll
+      for (int kt = 0; kt < NA; ++kt) ac[kt] = an[kt];
+    }
+  }
+}
+
+// grid = (splits, ceil(z_rows / 128), ceil(v_rows / kNtCols))
+__global__ __launch_bounds__(kThreads, 2) void lm_gemm_nt(const GemmNtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Zi = smem;                // [128][kTP]
+  float* Vi = smem + 128 * kTP;    // [kNtCols][kTP]
+  Lane L;
+  L.tid = threadIdx.x;
+  L.wave = __builtin_amdgcn_readfirstlane(L.tid >> 6);
+  L.ln = L.tid & 31;
+  L.lh = (L.tid >> 5) & 1;
+  const int zr0 = blockIdx.y * 128, vc0 = blockIdx.z * kNtCols;
+  const int zn = a.z_rows - zr0 < 128 ? a.z_rows - zr0 : 128;          // rows of Z staged (multiple of 32)
+  const int vn = a.v_rows - vc0 < kNtCols ? a.v_rows - vc0 : kNtCols;  // rows of V staged
+  const int na = vn >> 5;
+  const bool on = L.wave * 32 < zn;
+  constexpr int NKT = kNtCols / 32;
+  f32x16 dacc[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dacc[kt][r] = 0.0f;
+  float dbacc = 0.0f;
+  const bool do_db = a.db && blockIdx.z == 0;
+
+  for (int cb = blockIdx.x; cb < a.ncb; cb += gridDim.x) {
+    __syncthreads();
+    {
+      const float* zs = a.Z + ((long long)cb * a.z_rows + zr0) * kT;
+      const float* vs = a.V + ((long long)cb * a.v_rows + vc0) * kT;
+      const int zq = zn * 8, vq = vn * 8;
+      for (int q0 = 0; q0 < zq + vq; q0 += 4 * kThreads) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + u * kThreads + L.tid;
+          if (q < zq) v[u] = *reinterpret_cast<const f32x4*>(zs + 4 * q);
+          else if (q < zq + vq) v[u] = *reinterpret_cast<const f32x4*>(vs + 4 * (q - zq));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + u * kThreads + L.tid;
+          if (q < zq) *reinterpret_cast<f32x4*>(Zi + (q >> 3) * kTP + 4 * (q & 7)) = v[u];
+          else if (q < zq + vq) *reinterpret_cast<f32x4*>(Vi + ((q - zq) >> 3) * kTP + 4 * ((q - zq) & 7)) = v[u];
+        }
+      }
+    }
+    __syncthreads();
+    if (do_db && (cb % a.K) == 0 && L.tid < zn) dbacc += row_sum(Zi + L.tid * kTP);
+    if (on) {
+      const float* zrow = Zi + (L.wave * 32 + L.ln) * kTP + 4 * L.lh;
+      const float* arow = Vi + L.ln * kTP + 4 * L.lh;
+      switch (na) {  // wave-uniform
+        case 1: outer_block<1>(dacc, zrow, arow); break;
+        case 2: outer_block<2>(dacc, zrow, arow); break;
+        case 3: outer_block<3>(dacc, zrow, arow); break;
+        default: outer_block<4>(dacc, zrow, arow); break;
+      }
+    }
+  }
+  // one flush per workgroup
+  if (a.partial) {  // deterministic mode: plain stores of this split's partial; lm_reduce_partials sums them in order
+    float* P = a.partial + (long long)blockIdx.x * ((long long)a.z_rows * a.v_rows + a.z_rows);
+    if (on) {
+      float* base = P + (long long)(zr0 + L.wave * 32 + 4 * L.lh) * a.v_rows + vc0 + L.ln;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+        if (kt < na) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) base[(long long)((r & 3) + 8 * (r >> 2)) * a.v_rows + kt * 32] = dacc[kt][r];
+        }
+    }
+    if (do_db && L.tid < zn) P[(long long)a.z_rows * a.v_rows + zr0 + L.tid] = dbacc;
+    return;
+  }
+  if (on) {
+    float* base = a.dW + (long long)(zr0 + L.wave * 32 + 4 * L.lh) * a.v_rows + vc0 + L.ln;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+      if (kt < na) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(base + (long long)((r & 3) + 8 * (r >> 2)) * a.v_rows + kt * 32, dacc[kt][r]);
+      }
+  }
+  if (do_db && L.tid < zn) atomicAdd(a.db + zr0 + L.tid, dbacc);
+}
+
+// deterministic mode: out[i] += sum over splits (fixed order) of partial[s][i]
+__global__ void lm_reduce_partials(const float* partial, long long stride, int splits, float* dW, long long nW, float* db,
+                                   int nb) {
+  const long long total = nW + (db ? nb : 0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int k = 0; k < splits; ++k) s += partial[(long long)k * stride + i];
+    if (i < nW) dW[i] += s;
+    else db[i - nW] += s;
+  }
+}
+
+inline size_t lm_gemm_nt_lds_bytes() { return sizeof(float) * (size_t)(128 + kNtCols) * kTP; }
+
+}  // namespace lm
+}  // namespace pinn

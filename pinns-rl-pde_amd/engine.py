@@ -53,7 +53,7 @@ class NetProgram:
 
     def __init__(self, arch: str, activation: str, input_dim: int, widths: Sequence[int], tensors: Sequence[Tensor],
                  trainable: Sequence[bool], mapping_size: int = 0, omega_0: float = 0.0, ln_eps: float = 1e-5,
-                 num_blocks: int = 0):
+                 num_blocks: int = 0, layer_norm: bool = False, deterministic: bool = False):
         if arch not in _lib.ARCH:
             raise NotImplementedError(f"pinnrl_amd: architecture '{arch}' has no fused HIP kernel")
         if activation not in _lib.ACT:
@@ -71,13 +71,32 @@ class NetProgram:
         d.act_param = float(omega_0)
         d.ln_eps = float(ln_eps)
         d.num_blocks = int(num_blocks)
+        d.flags = (_lib.PINN_FLAG_LAYER_NORM if layer_norm else 0) | (_lib.PINN_FLAG_DETERMINISTIC if deterministic else 0)
         self.desc = d
         self.arch = arch
         self.tensors = list(tensors)
         self.trainable = list(trainable)
         self.input_dim = int(input_dim)
 
+    def set_deterministic(self, on: bool = True) -> None:
+        """Weight gradients reduced in a fixed order (bit-identical across launches on the same inputs)."""
+        if on:
+            self.desc.flags |= _lib.PINN_FLAG_DETERMINISTIC
+        else:
+            self.desc.flags &= ~_lib.PINN_FLAG_DETERMINISTIC
+
+    def set_layer_major(self, on: bool = True) -> None:
+        """Engine hint: take the layer-major engine even where the fused tile-major kernel applies."""
+        if on:
+            self.desc.flags |= _lib.PINN_FLAG_LAYER_MAJOR
+        else:
+            self.desc.flags &= ~_lib.PINN_FLAG_LAYER_MAJOR
+
     # -- pointer tables ---------------------------------------------------------------------
+    @property
+    def num_tensors(self) -> int:
+        return len(self.tensors)
+
     def _weight_ptrs(self):
         for p in self.tensors:
             if p.dtype != torch.float32 or not p.is_contiguous():
@@ -112,20 +131,41 @@ class NetProgram:
         return total
 
 
-_workspaces: Dict[torch.device, Tensor] = {}
+_workspaces: Dict[Tuple[torch.device, int], Tensor] = {}
+_graph_pinned: Dict[Tuple[torch.device, int], bool] = {}
+_retired: List[Tensor] = []  # buffers a captured HIP graph still points into: kept alive for the life of the process
 
 
 def _workspace(dev: torch.device, nbytes: int) -> Tensor:
-    """Reusable scratch owned by PyTorch's caching allocator (the library never allocates)."""
-    ws = _workspaces.get(dev)
+    """Reusable scratch owned by PyTorch's caching allocator (the library never allocates), one per (device, stream).
+
+    A HIP graph bakes the buffer's address into its kernel arguments, so a buffer that was handed out during a
+    capture is never returned to the allocator: when a later, larger request replaces it, it is parked in
+    `_retired` instead of being freed (a freed block could be re-issued and the graph's replays would write over it)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None and _graph_pinned.get(key):
+            _retired.append(ws)
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
-        _workspaces[dev] = ws
+        _workspaces[key] = ws
+        _graph_pinned[key] = False
+    if torch.cuda.is_current_stream_capturing():
+        _graph_pinned[key] = True
     return ws
 
 
 def _stream(dev: torch.device) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _scratch(prog: "NetProgram", dev: torch.device, N: int, nt: int, nx: int, backward: bool):
+    """(tensor | None, data_ptr, nbytes) of the scratch one call needs (records of the layer-major engine / tape)."""
+    nbytes = _lib.load().pinn_workspace_bytes(ctypes.byref(prog.desc), N, nt, nx, 1 if backward else 0)
+    if nbytes == 0:
+        return None, None, 0
+    ws = _workspace(dev, nbytes)
+    return ws, ws.data_ptr(), ws.numel()
 
 
 def _prep_points(prog: NetProgram, x: Tensor, t: Tensor) -> Tuple[Tensor, Tensor, int]:
@@ -167,9 +207,10 @@ def jets_forward(prog: NetProgram, x: Tensor, t: Tensor, nt: int, nx: int) -> Te
     if N == 0:
         return out
     optr = (ctypes.c_void_p * K)(*[out[s].data_ptr() for s in range(K)])
+    ws, wptr, wn = _scratch(prog, dev, N, nt, nx, False)
     with torch.cuda.device(dev):
-        _lib.check(lib.pinn_jet_forward(ctypes.byref(prog.desc), prog._weight_ptrs(), x.data_ptr(), t.data_ptr(), N,
-                                        nt, nx, optr, _stream(dev)))
+        _lib.check(lib.pinn_jet_forward(ctypes.byref(prog.desc), prog._weight_ptrs(), prog.num_tensors, x.data_ptr(),
+                                        t.data_ptr(), N, nt, nx, optr, wptr, wn, _stream(dev)))
     return out
 
 
@@ -200,11 +241,10 @@ def jets_backward(prog: NetProgram, x: Tensor, t: Tensor, nt: int, nx: int, cot:
     cot = _f32c(cot)
     assert cot.shape == (K, N)
     cptr = (ctypes.c_void_p * K)(*[cot[s].data_ptr() for s in range(K)])
-    nbytes = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), N, nt, nx)
-    ws = _workspace(dev, nbytes)
+    ws, wptr, wn = _scratch(prog, dev, N, nt, nx, True)
     with torch.cuda.device(dev):
-        _lib.check(lib.pinn_jet_backward(ctypes.byref(prog.desc), prog._weight_ptrs(), x.data_ptr(), t.data_ptr(), N, nt,
-                                         nx, cptr, _grad_ptrs(prog, flat_grad), ws.data_ptr(), ws.numel(), _stream(dev)))
+        _lib.check(lib.pinn_jet_backward(ctypes.byref(prog.desc), prog._weight_ptrs(), prog.num_tensors, x.data_ptr(),
+                                         t.data_ptr(), N, nt, nx, cptr, _grad_ptrs(prog, flat_grad), wptr, wn, _stream(dev)))
 
 
 def residual_forward(prog: NetProgram, pd, x: Tensor, t: Tensor, want_residual: bool = True) -> Tuple[Optional[Tensor], Tensor]:
@@ -215,10 +255,13 @@ def residual_forward(prog: NetProgram, pd, x: Tensor, t: Tensor, want_residual: 
     r = torch.empty((N, 1), dtype=torch.float32, device=dev) if want_residual else None
     s = torch.zeros(1, dtype=torch.float32, device=dev)
     if N:
+        nt, nx = pde_streams(pd)
+        ws, wptr, wn = _scratch(prog, dev, N, nt, nx, False)
         with torch.cuda.device(dev):
-            _lib.check(lib.pinn_residual_forward(ctypes.byref(prog.desc), prog._weight_ptrs(), ctypes.byref(pd),
-                                                 x.data_ptr(), t.data_ptr(), N, r.data_ptr() if want_residual else None,
-                                                 s.data_ptr(), _stream(dev)))
+            _lib.check(lib.pinn_residual_forward(ctypes.byref(prog.desc), prog._weight_ptrs(), prog.num_tensors,
+                                                 ctypes.byref(pd), x.data_ptr(), t.data_ptr(), N,
+                                                 r.data_ptr() if want_residual else None, s.data_ptr(), wptr, wn,
+                                                 _stream(dev)))
     return r, s
 
 
@@ -232,13 +275,12 @@ def residual_loss_grad(prog: NetProgram, pd, x: Tensor, t: Tensor, grad_scale: f
     s = loss_sum if loss_sum is not None else torch.zeros(1, dtype=torch.float32, device=dev)
     if N:
         nt, nx = pde_streams(pd)
-        nbytes = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), N, nt, nx)
-        ws = _workspace(dev, nbytes)
+        ws, wptr, wn = _scratch(prog, dev, N, nt, nx, True)
         with torch.cuda.device(dev):
-            _lib.check(lib.pinn_residual_loss_grad(ctypes.byref(prog.desc), prog._weight_ptrs(), ctypes.byref(pd),
-                                                   x.data_ptr(), t.data_ptr(), N, float(grad_scale),
+            _lib.check(lib.pinn_residual_loss_grad(ctypes.byref(prog.desc), prog._weight_ptrs(), prog.num_tensors,
+                                                   ctypes.byref(pd), x.data_ptr(), t.data_ptr(), N, float(grad_scale),
                                                    r.data_ptr() if want_residual else None, s.data_ptr(),
-                                                   _grad_ptrs(prog, flat_grad), ws.data_ptr(), ws.numel(), _stream(dev)))
+                                                   _grad_ptrs(prog, flat_grad), wptr, wn, _stream(dev)))
     return r, s
 
 
@@ -252,12 +294,11 @@ def residual_backward(prog: NetProgram, pd, x: Tensor, t: Tensor, res_bar: Tenso
     res_bar = _f32c(res_bar).reshape(-1)
     assert res_bar.numel() == N
     nt, nx = pde_streams(pd)
-    nbytes = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), N, nt, nx)
-    ws = _workspace(dev, nbytes)
+    ws, wptr, wn = _scratch(prog, dev, N, nt, nx, True)
     with torch.cuda.device(dev):
-        _lib.check(lib.pinn_residual_backward(ctypes.byref(prog.desc), prog._weight_ptrs(), ctypes.byref(pd), x.data_ptr(),
-                                              t.data_ptr(), N, res_bar.data_ptr(), _grad_ptrs(prog, flat_grad),
-                                              ws.data_ptr(), ws.numel(), _stream(dev)))
+        _lib.check(lib.pinn_residual_backward(ctypes.byref(prog.desc), prog._weight_ptrs(), prog.num_tensors,
+                                              ctypes.byref(pd), x.data_ptr(), t.data_ptr(), N, res_bar.data_ptr(),
+                                              _grad_ptrs(prog, flat_grad), wptr, wn, _stream(dev)))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -194,10 +194,8 @@ class FeedForwardNetwork(BaseNetwork):  # feedforward.py:9-73
 
     def _program_spec(self):
         _dropout_guard(self.dropout_rate, "FeedForwardNetwork")
-        if self.use_layer_norm:
-            raise NotImplementedError("FeedForwardNetwork(layer_norm=True) has no fused HIP kernel yet (SURVEY §8f rank 3)")
         return dict(arch="feedforward", activation=self.activation_name, input_dim=self.input_dim,
-                    widths=self.hidden_dims + [self.output_dim])
+                    widths=self.hidden_dims + [self.output_dim], layer_norm=bool(self.use_layer_norm))
 
 
 class SIRENLayer(nn.Module):  # siren.py:11-46

@@ -475,8 +475,8 @@ class BlackScholesEquation(PDEBase):
         return (self.sigma, self.r)
 
     def _residual_from_jets(self, j, x, nt, nx):
-        if self.dimension > 1:
-            return j[1]
+        if self.dimension > 1:  # black_scholes.py:84-91: the spatial terms vanish, -rV does not
+            return j[1] - self.r * j[0]
         S = x[:, 0]
         return j[1] + 0.5 * self.sigma**2 * S**2 * j[nt + 2] + self.r * S * j[nt + 1] - self.r * j[0]
 

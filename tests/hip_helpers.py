@@ -19,7 +19,8 @@ def program_from_spec(spec, sd, device):
                             mapping_size=spec.mapping_size), names
     if spec.architecture == "feedforward":
         widths = list(spec.dims()) + [spec.output_dim]
-        return E.NetProgram("feedforward", spec.activation, spec.input_dim, widths, tensors, trainable), names
+        return E.NetProgram("feedforward", spec.activation, spec.input_dim, widths, tensors, trainable,
+                            layer_norm=bool(spec.layer_norm)), names
     if spec.architecture == "siren":
         widths = list(spec.dims()) + [spec.output_dim]
         return E.NetProgram("siren", "sin", spec.input_dim, widths, tensors, trainable, omega_0=spec.omega_0), names

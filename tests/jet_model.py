@@ -269,6 +269,10 @@ def pde_residual(name: str, p: Mapping, j: List[Tensor], x0: Tensor, NT: int, NX
         if name == "allen_cahn":
             d[0], d[1] = 3 * u * u - 1, one
             return T(1) - u + u**3, d
+        if name == "black_scholes":
+            rr = p.get("r", 0.05)
+            d[0], d[1] = -rr * one, one
+            return T(1) - rr * u, d
         d[1] = one  # every other >=2-D residual keeps only its u_t term (+ nothing that survives)
         if name == "burgers" or name == "kdv" or name == "heat" or name == "cahn_hilliard" or name == "convection":
             return T(1), d

@@ -41,21 +41,58 @@ def test_descriptor_queries_without_a_gpu():
     spec, pde, sd, a, m = load_case("burgers_fourier_4x128")
     prog = E.NetProgram("fourier", "tanh", 2, [128, 128, 128, 1], list(sd.values()), [False] + [True] * 8, mapping_size=32)
     assert prog.flops_per_point() == 82304
-    nbytes = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), 49729, 1, 2)
-    assert nbytes > 0 and nbytes % 16 == 0
-    bad = E.NetProgram("fourier", "tanh", 2, [100, 1], [sd["model.fourier.B"]] + [torch.zeros(1)] * 4, [False] + [True] * 4,
+    assert lib.pinn_num_tensors(ctypes.byref(prog.desc)) == 9 == prog.num_tensors
+    # headline network: the fused tile-major kernel — no scratch forward, one tape slab per workgroup in reverse
+    assert lib.pinn_workspace_bytes(ctypes.byref(prog.desc), 49729, 1, 2, 0) == 0
+    nbytes = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), 49729, 1, 2, 1)
+    assert nbytes == 4 * 4 * 16 * 256 * 4 * 256  # (3 layers + encoding) x K = 4 streams x 16 regs x 256 threads x 4 B x 256 CUs
+    # the same network through the layer-major engine: packed parameters + records, forward and reverse
+    prog.set_layer_major(True)
+    f_lm = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), 49729, 1, 2, 0)
+    b_lm = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), 49729, 1, 2, 1)
+    assert 0 < f_lm < b_lm and f_lm % 256 == 0
+    prog.set_layer_major(False)
+    # widths that are not multiples of 32 are legal (packed and zero-padded): reference defaults are 124 and 512
+    odd = E.NetProgram("fourier", "tanh", 2, [100, 1], [sd["model.fourier.B"]] + [torch.zeros(1)] * 4, [False] + [True] * 4,
                        mapping_size=32)
-    assert lib.pinn_workspace_bytes(ctypes.byref(bad.desc), 100, 1, 2) == 0  # width 100: not a multiple of 32
-    # deepest weight tables: 4 attention layers = 68 tensors, 6 ResNet blocks = 52 (the sizing path once used a
-    # 50-entry scratch table); 9 tape slots per attention layer, 256 workgroups, K = 2 streams of 16 regs x 256 threads
+    assert lib.pinn_workspace_bytes(ctypes.byref(odd.desc), 100, 1, 2, 1) > 0
+    bad = E.NetProgram("fourier", "tanh", 2, [2000, 1], [sd["model.fourier.B"]] + [torch.zeros(1)] * 4, [False] + [True] * 4,
+                       mapping_size=32)
+    assert lib.pinn_workspace_bytes(ctypes.byref(bad.desc), 100, 1, 2, 1) == 0  # width 2000 > 1024
+    assert lib.pinn_num_tensors(ctypes.byref(bad.desc)) == -2 and b"1024" in lib.pinn_last_error()
+    # deepest weight tables: 4 attention layers = 68 tensors, 6 ResNet blocks = 52
     import oracle as O
     from hip_helpers import program_from_spec
     aspec = O.ArchSpec("attention", input_dim=3, hidden_dim=128, num_layers=4, activation="gelu", num_heads=4)
     aprog, _ = program_from_spec(aspec, O.init_state_dict(aspec, seed=0), torch.device("cpu"))
-    assert lib.pinn_workspace_bytes(ctypes.byref(aprog.desc), 1000000, 1, 0) == 9 * 4 * 2 * 16 * 256 * 4 * 256
+    assert lib.pinn_num_tensors(ctypes.byref(aprog.desc)) == 68 == aprog.num_tensors
+    assert lib.pinn_workspace_bytes(ctypes.byref(aprog.desc), 1000000, 1, 0, 1) > 0
     rspec = O.ArchSpec("resnet", hidden_dim=256, num_layers=6, num_blocks=6)
     rprog, _ = program_from_spec(rspec, O.init_state_dict(rspec, seed=0), torch.device("cpu"))
-    assert lib.pinn_workspace_bytes(ctypes.byref(rprog.desc), 100000, 1, 2) > 0
+    assert lib.pinn_num_tensors(ctypes.byref(rprog.desc)) == 52 == rprog.num_tensors
+    assert lib.pinn_workspace_bytes(ctypes.byref(rprog.desc), 100000, 1, 2, 1) > 0
+    fspec = O.ArchSpec("feedforward", hidden_dim=124, num_layers=3, layer_norm=True)
+    fprog, _ = program_from_spec(fspec, O.init_state_dict(fspec, seed=0), torch.device("cpu"))
+    assert lib.pinn_num_tensors(ctypes.byref(fprog.desc)) == 14 == fprog.num_tensors
+
+
+def test_weight_table_length_is_validated_before_any_entry_is_read():
+    """ABI v2: every entry point takes the table length; a short (or long) table is refused with PINN_ERR_BAD_DESC
+    before a single pointer is dereferenced (round 1 indexed the table on trust)."""
+    lib = _lib.load()
+    from pinnrl_amd import engine as E
+
+    spec, pde, sd, a, m = load_case("cahn_hilliard2d_attention_2x32")
+    from hip_helpers import program_from_spec
+    prog, _ = program_from_spec(spec, sd, torch.device("cpu"))
+    n = prog.num_tensors
+    short = (ctypes.c_void_p * 3)(1, 2, 3)  # three bogus entries: must never be read
+    outs = (ctypes.c_void_p * 2)(8, 8)
+    for bad_n in (3, n - 1, n + 1, 0, -5):
+        rc = lib.pinn_jet_forward(ctypes.byref(prog.desc), short, bad_n, 16, 16, 5, 1, 0, outs, None, 0, None)
+        assert rc == -1 and b"entries" in lib.pinn_last_error(), (bad_n, rc, lib.pinn_last_error())
+    rc = lib.pinn_jet_forward(ctypes.byref(prog.desc), None, n, 16, 16, 5, 1, 0, outs, None, 0, None)
+    assert rc == -1 and b"null" in lib.pinn_last_error()
 
 
 def test_model_config_matches_reference_semantics():
