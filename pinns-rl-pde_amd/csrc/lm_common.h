@@ -29,7 +29,7 @@ namespace pinn {
 namespace lm {
 
 constexpr int kMaxNodes = 40;   // GEMM nodes of one network (attention: 4 per layer)
-constexpr int kMaxPack = 112;   // tensors in one pack / unpack launch
+constexpr int kMaxPack = 144;   // tensors in one pack / unpack launch (state_dict entries + one transposed copy per GEMM weight)
 
 __host__ __device__ inline int round32(int v) { return (v + 31) & ~31; }
 

@@ -68,14 +68,16 @@ int num_cus() {
   return 256;
 }
 
-// bytes of one record per chunk the sizing aims at (short-lived records of neighbouring launches then share the
-// 256 MB Infinity Cache); PINN_LM_RECORD_MB overrides it, read once
+// Bytes of one record per chunk the sizing aims at; PINN_LM_RECORD_MB overrides it, read once.  Measured on MI355X
+// (tools/bench_configs.py, C3 / C4 / C5): bigger is faster all the way — 96 MB 41.5 / 46.0 / 177 ms, 512 MB 33.8 /
+// 36.8 / 143 ms: what counts is full waves of work per launch and few one-off weight-gradient flushes, not Infinity
+// Cache residency of the records.  512 MB keeps a 10^6-point batch of the widest supported network within ~30 GB.
 size_t record_target_bytes() {
   static size_t v = 0;
   if (!v) {
     const char* e = getenv("PINN_LM_RECORD_MB");
     const long mb = e ? atol(e) : 0;
-    v = (size_t)(mb > 0 ? mb : 96) << 20;
+    v = (size_t)(mb > 0 ? mb : 512) << 20;
   }
   return v;
 }
@@ -155,7 +157,7 @@ int build_program(const PinnNetDesc* d, Program& P, char* err, size_t en) {
   P.din = d->input_dim;
   P.n_tensors = expected_tensors(d);
   if (P.n_tensors < 0) return failf(err, en, PINN_ERR_UNSUPPORTED, "architecture id %d has no kernel", d->arch);
-  if (P.n_tensors > kMaxPack) return failf(err, en, PINN_ERR_UNSUPPORTED, "%d tensors exceed the pack table (%d)", P.n_tensors, kMaxPack);
+  if (P.n_tensors + kMaxNodes > kMaxPack) return failf(err, en, PINN_ERR_UNSUPPORTED, "%d tensors exceed the pack table (%d)", P.n_tensors, kMaxPack - kMaxNodes);
   P.ln_eps = d->ln_eps > 0.0f ? d->ln_eps : 1e-5f;
   const int act = d->arch == PINN_ARCH_SIREN ? PINN_ACT_SIN : d->activation;
   const float par = act_param_of(act, d->act_param);
@@ -368,6 +370,21 @@ void make_layout(const Program& P, long long N, int K, bool bwd, bool determinis
     }
     off += (size_t)it.rows_p * it.cols_p;
   }
+  // a transposed copy of every GEMM weight: Vbar = W^T Zbar then runs as the rows form too (16-byte loads along the
+  // reduction axis instead of 16 dword loads per 32-deep chunk: 154 -> 116 us per launch at width 256)
+  for (int m = 0; m < P.n_nodes; ++m) {
+    PackItem& it = L.tab.item[P.n_tensors + m];
+    it.src = nullptr;
+    it.user_grad = nullptr;
+    it.off = (unsigned)off;
+    it.rows = P.node[m].Hout;
+    it.cols = P.node[m].Hin;
+    it.transpose = 1;
+    it.rows_p = round32(P.node[m].Hin);
+    it.cols_p = round32(P.node[m].Hout);
+    off += (size_t)it.rows_p * it.cols_p;
+  }
+  L.tab.n = P.n_tensors + P.n_nodes;
   L.n_packed = off;
   // chunk size: the widest record of a chunk stays near the target
   int hmax = P.head.H;
@@ -545,9 +562,10 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
     L.tab.item[i].src = c.weights[i];
     L.tab.item[i].user_grad = (c.bwd && c.grads && !P.transpose[i]) ? c.grads[i] : nullptr;
   }
+  for (int m = 0; m < P.n_nodes; ++m) L.tab.item[P.n_tensors + m].src = c.bwd ? c.weights[P.node[m].w] : nullptr;
   float* params = ws + L.params;
   float* grads = ws + L.grads;
-  hipLaunchKernelGGL(lm_pack_kernel, dim3(8, P.n_tensors), dim3(256), 0, st, L.tab, params);
+  hipLaunchKernelGGL(lm_pack_kernel, dim3(8, L.tab.n), dim3(256), 0, st, L.tab, params);
   LM_CHECK(hipGetLastError());
   if (c.bwd) LM_CHECK(hipMemsetAsync(grads, 0, L.n_packed * sizeof(float), st));
   auto pp = [&](int idx) -> const float* { return idx >= 0 ? params + L.tab.item[idx].off : nullptr; };
@@ -704,24 +722,26 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
         g.v_rows = round32(nd.Hin);
         g.ncb = ncb;
         g.K = K;
-        const int gy = (g.z_rows + 127) / 128, gz = (g.v_rows + kNtCols - 1) / kNtCols;
-        int gx = 2 * cus / (gy * gz);
+        const bool big = g.z_rows >= 256 && g.v_rows >= 256;  // 256 x 256 blocks on eight waves
+        const int gy = big ? (g.z_rows + kNt8 - 1) / kNt8 : (g.z_rows + 127) / 128;
+        const int gz = big ? (g.v_rows + kNt8 - 1) / kNt8 : (g.v_rows + kNtCols - 1) / kNtCols;
+        // splits: fill the chip, but leave every workgroup >= 12 column blocks to amortise its one-off flush
+        // (a 128 x 128 block is 64 KB of float atomics; at 3 column blocks per workgroup the flush was 3x the GEMM)
+        int gx = (big ? cus : 2 * cus) / (gy * gz);
+        if (gx > ncb / 12) gx = ncb / 12;
         if (gx < 1) gx = 1;
-        if (gx > ncb) gx = ncb;
         if (gx > 512) gx = 512;
-        const size_t lds = lm_gemm_nt_lds_bytes();
-        LM_CHECK(allow_lds(reinterpret_cast<const void*>(lm_gemm_nt), lds));
+        const size_t lds = big ? lm_gemm_nt8_lds_bytes() : lm_gemm_nt_lds_bytes();
+        const void* kern = big ? reinterpret_cast<const void*>(lm_gemm_nt8) : reinterpret_cast<const void*>(lm_gemm_nt);
+        LM_CHECK(allow_lds(kern, lds));
+        const size_t stride = (size_t)g.z_rows * g.v_rows + g.z_rows;
+        if (c.deterministic) g.partial = ws + L.partial;  // every element of a split's block is stored by exactly one workgroup
+        if (big) hipLaunchKernelGGL(lm_gemm_nt8, dim3(gx, gy, gz), dim3(512), lds, st, g);
+        else hipLaunchKernelGGL(lm_gemm_nt, dim3(gx, gy, gz), dim3(kThreads), lds, st, g);
+        LM_CHECK(hipGetLastError());
         if (c.deterministic) {
-          g.partial = ws + L.partial;
-          // every element of a split's partial block is stored by exactly one workgroup (blockIdx.y, blockIdx.z)
-          const size_t stride = (size_t)g.z_rows * g.v_rows + g.z_rows;
-          hipLaunchKernelGGL(lm_gemm_nt, dim3(gx, gy, gz), dim3(kThreads), lds, st, g);
-          LM_CHECK(hipGetLastError());
           hipLaunchKernelGGL(lm_reduce_partials, dim3(256), dim3(256), 0, st, g.partial, (long long)stride, gx, g.dW,
                              (long long)g.z_rows * g.v_rows, g.db, g.z_rows);
-          LM_CHECK(hipGetLastError());
-        } else {
-          hipLaunchKernelGGL(lm_gemm_nt, dim3(gx, gy, gz), dim3(kThreads), lds, st, g);
           LM_CHECK(hipGetLastError());
         }
       }
@@ -732,21 +752,21 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       if (pro.src_kind == SRC_COORDS_LINEAR && !gp(pro.enc_w) && !gp(pro.enc_b) && pro.ln_g < 0 && pro.skip_node < 0) continue;
       GemmArgs g;
       memset(&g, 0, sizeof(g));
-      g.W = pp(nd.w);
+      g.W = params + L.tab.item[P.n_tensors + m].off;  // W^T, packed (Hin_p x Hout_p)
       g.X = zbar;
       g.Y = ws + L.Vbar[m];
       g.add0 = extra[m][0];
       g.add1 = extra[m][1];
-      g.w_rows = round32(nd.Hout);
-      g.w_cols = round32(nd.Hin);
+      g.w_rows = round32(nd.Hin);
+      g.w_cols = round32(nd.Hout);
       g.ncb = ncb;
       g.K = K;
-      LM_CHECK(launch_gemm<true>(g, st));
+      LM_CHECK(launch_gemm<false>(g, st));
       if (!pro.identity() && (rc = run_ew_bwd(pro, m, ws + L.Vbar[m])) != PINN_OK) return rc;
     }
   }
   if (c.bwd) {
-    hipLaunchKernelGGL(lm_unpack_kernel, dim3(8, P.n_tensors), dim3(256), 0, st, L.tab, grads);
+    hipLaunchKernelGGL(lm_unpack_kernel, dim3(8, L.tab.n), dim3(256), 0, st, L.tab, grads);
     LM_CHECK(hipGetLastError());
   }
 #undef LM_CHECK

@@ -316,6 +316,115 @@ __global__ __launch_bounds__(kThreads, 2) void lm_gemm_nt(const GemmNtArgs a) {
   if (do_db && L.tid < zn) atomicAdd(a.db + zr0 + L.tid, dbacc);
 }
 
+// Width >= 256: eight waves own a 256 x 256 block of dW (128 accumulator registers per lane at two waves per SIMD),
+// so every staged byte of Z and V feeds twice the MFMAs of the 128 x 128 form (64 instead of 32 FLOP per byte —
+// the 128-wide blocks were bound by record traffic, not by the matrix pipe).  The next column block's rows travel in
+// registers while the current one is multiplied (one barrier per column block).
+// grid = (splits, ceil(z_rows / 256), ceil(v_rows / 256)), 512 threads.
+constexpr int kNt8 = 256;
+
+__global__ __launch_bounds__(512, 2) void lm_gemm_nt8(const GemmNtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kImg = 2 * kNt8 * kTP;  // floats per buffer: Z rows then V rows
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = tid & 31, lh = (tid >> 5) & 1;
+  const int zr0 = blockIdx.y * kNt8, vc0 = blockIdx.z * kNt8;
+  const int zn = a.z_rows - zr0 < kNt8 ? a.z_rows - zr0 : kNt8;
+  const int vn = a.v_rows - vc0 < kNt8 ? a.v_rows - vc0 : kNt8;
+  const int na = vn >> 5;
+  const bool on = wave * 32 < zn;
+  f32x16 dacc[8];
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dacc[kt][r] = 0.0f;
+  float dbacc = 0.0f;
+  const bool do_db = a.db && blockIdx.z == 0;
+  const int zq = zn * 8, vq = vn * 8;  // float4 per staged block
+  f32x4 pre[8];
+  auto fetch = [&](int cb) {
+    const float* zs = a.Z + ((long long)cb * a.z_rows + zr0) * kT;
+    const float* vs = a.V + ((long long)cb * a.v_rows + vc0) * kT;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = u * 512 + tid;
+      if (q < zq) pre[u] = *reinterpret_cast<const f32x4*>(zs + 4 * q);
+      else if (q < zq + vq) pre[u] = *reinterpret_cast<const f32x4*>(vs + 4 * (q - zq));
+    }
+  };
+  auto stash = [&](float* img) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = u * 512 + tid;
+      if (q < zq) *reinterpret_cast<f32x4*>(img + (q >> 3) * kTP + 4 * (q & 7)) = pre[u];
+      else if (q < zq + vq) *reinterpret_cast<f32x4*>(img + (kNt8 + ((q - zq) >> 3)) * kTP + 4 * ((q - zq) & 7)) = pre[u];
+    }
+  };
+  int buf = 0;
+  int cb = blockIdx.x;
+  if (cb < a.ncb) {
+    fetch(cb);
+    stash(smem);
+  }
+  __syncthreads();
+  for (; cb < a.ncb; cb += gridDim.x) {
+    const int nxt = cb + gridDim.x;
+    if (nxt < a.ncb) fetch(nxt);  // in flight under the MFMAs below
+    const float* img = smem + buf * kImg;
+    if (do_db && (cb % a.K) == 0 && tid < zn) dbacc += row_sum(img + tid * kTP);
+    if (on) {
+      const float* zrow = img + (wave * 32 + ln) * kTP + 4 * lh;
+      const float* arow = img + (kNt8 + ln) * kTP + 4 * lh;
+      // operands of point group g: one row segment of Z and eight of V per lane; the reads of group g + 1 are issued
+      // behind the first half of group g's MFMAs (a full second set of eight would push the prefetch registers of
+      // the next column block into scratch, and a spilled prefetch waits for its loads on the spot)
+      f32x4 zc, ac[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        zc = *reinterpret_cast<const f32x4*>(zrow + 8 * g);
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+          if (kt < na) ac[kt] = *reinterpret_cast<const f32x4*>(arow + kt * 32 * kTP + 8 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int kt = 0; kt < 8; ++kt)
+            if (kt < na) dacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zc[i], ac[kt][i], dacc[kt], 0, 0, 0);
+      }
+    }
+    if (nxt < a.ncb) stash(smem + (buf ^ 1) * kImg);
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (a.partial) {
+    float* P = a.partial + (long long)blockIdx.x * ((long long)a.z_rows * a.v_rows + a.z_rows);
+    if (on) {
+      float* base = P + (long long)(zr0 + wave * 32 + 4 * lh) * a.v_rows + vc0 + ln;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+        if (kt < na) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) base[(long long)((r & 3) + 8 * (r >> 2)) * a.v_rows + kt * 32] = dacc[kt][r];
+        }
+    }
+    if (do_db && tid < zn) P[(long long)a.z_rows * a.v_rows + zr0 + tid] = dbacc;
+    return;
+  }
+  if (on) {
+    float* base = a.dW + (long long)(zr0 + wave * 32 + 4 * lh) * a.v_rows + vc0 + ln;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+      if (kt < na) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(base + (long long)((r & 3) + 8 * (r >> 2)) * a.v_rows + kt * 32, dacc[kt][r]);
+      }
+  }
+  if (do_db && tid < zn) atomicAdd(a.db + zr0 + tid, dbacc);
+}
+
+inline size_t lm_gemm_nt8_lds_bytes() { return sizeof(float) * (size_t)2 * 2 * kNt8 * kTP; }
+
 // deterministic mode: out[i] += sum over splits (fixed order) of partial[s][i]
 __global__ void lm_reduce_partials(const float* partial, long long stride, int splits, float* dW, long long nW, float* db,
                                    int nb) {

@@ -61,7 +61,6 @@ static int num_cus() {
   return 256;  // MI355X; used only for sizing when no device is visible (CPU-side workspace queries)
 }
 
-constexpr size_t kLdsLimit = 160 * 1024;
 
 // PINN_KERNEL=lm routes every architecture through the layer-major engine (tests run both engines on the MLP
 // family).  Read once per process: the ABI itself carries no mutable state.

@@ -28,7 +28,7 @@ def build(tag, dev):
     cfg = Config.__new__(Config)
     cfg.device = dev
     cfg.model = ModelConfig(input_dim=spec.input_dim, hidden_dim=spec.hidden_dim, output_dim=1, num_layers=spec.num_layers,
-                            activation=spec.activation, architecture=spec.architecture)
+                            activation=spec.activation, architecture=spec.architecture, layer_norm=spec.layer_norm)
     cfg.model.mapping_size, cfg.model.scale = spec.mapping_size, spec.scale
     cfg.model.omega_0, cfg.model.num_heads = spec.omega_0, spec.num_heads
     if spec.architecture == "resnet":

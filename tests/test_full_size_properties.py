@@ -39,17 +39,29 @@ def _oracle_spec(tag):
     }[tag]
 
 
-@pytest.mark.parametrize("tag", ["C1", "C2", "C3", "C4", "C5"])
+@pytest.mark.parametrize("tag", ["C1", "C2", "C3-explore", "C3-exploit", "C4", "C5"])
 def test_full_size_configuration(tag, dev):
     import bench_configs as B
     import oracle as O
     from pinnrl_amd import engine as E
+    from pinnrl_amd.rl import RLAgent
 
+    tag, _, mode = tag.partition("-")
     name, net, eq, n_req = B.CONFIGS[tag]()
     torch.manual_seed(1)
     if tag == "C3":
-        x = torch.rand(n_req, 1, device=dev) * 2 - 1
-        t = torch.rand(n_req, 1, device=dev)
+        # BASELINE C3 samples with the DQN agent (pinnrl/pdes/pde_base.py:961-1073): the policy network scores the
+        # 100 x 100 grid on the device.  epsilon = 1: explore branch, every point collapses onto the (x_min, t_min)
+        # corner; epsilon = 0: exploit branch.  Either way exactly N points come back, duplicates included.
+        agent = RLAgent(state_dim=2, action_dim=1, hidden_dim=64, device=dev)
+        agent.epsilon = 1.0 if mode == "explore" else 0.0
+        eq.rl_agent = agent
+        x, t = eq.generate_collocation_points(n_req, strategy="adaptive")
+        assert x.shape == (n_req, 1) and t.shape == (n_req, 1) and x.is_cuda
+        if mode == "explore":
+            assert float(x.max()) < -0.9 and float(t.max()) < 0.1
+        else:
+            assert float(x.max() - x.min()) > 1.0 and float(t.max() - t.min()) > 0.5  # spread over the domain
     else:
         x, t = eq.generate_collocation_points(n_req, strategy="uniform")
     N = x.shape[0]
@@ -78,5 +90,5 @@ def test_full_size_configuration(tag, dev):
     sd = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
     idx = torch.linspace(0, N - 1, 256).long()
     xs, ts = x[idx.to(dev)].cpu().double(), t[idx.to(dev)].cpu().double()
-    r_o = O.compute_residual(pspec, lambda inp: O.network_forward(spec, sd, inp), xs, ts).detach()
+    r_o = O.compute_residual(pspec, lambda inp: O.network_forward(spec, sd, inp, "composite"), xs, ts).detach()
     assert rel_l2(r[idx.to(dev)].cpu(), r_o) <= 1e-5, f"{tag}: {rel_l2(r[idx.to(dev)].cpu(), r_o):.3e}"
