@@ -490,8 +490,18 @@ hipError_t launch_head(int nt, int nx, const HeadArgs& a, int fpt, int grid, hip
   return hipErrorInvalidValue;
 }
 
+int gemm_prefetch_mode() {  // PINN_LM_PREFETCH=0|1 (experiments), read once
+  static const int v = [] {
+    const char* e = getenv("PINN_LM_PREFETCH");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 template <bool COLS>
-hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
+hipError_t launch_gemm(const GemmArgs& g0, hipStream_t st) {
+  GemmArgs g = g0;
+  g.prefetch = gemm_prefetch_mode();
   const int out_rows = COLS ? g.w_cols : g.w_rows;
   const int depth = COLS ? g.w_rows : g.w_cols;
   const int items = (g.ncb + kCB - 1) / kCB;

@@ -33,6 +33,7 @@ struct GemmArgs {
   int w_rows, w_cols;
   int ncb;            // column blocks = tiles * K
   int K;              // streams per tile: bias goes to blocks with cb % K == 0
+  int prefetch;       // 0: next stage requested after the MFMAs (under the epilogue); 1: before them
 };
 
 struct WFrag16 {
@@ -97,6 +98,11 @@ __device__ __forceinline__ void gemm_core(f32x16 (&acc)[kCB], const float* W, in
 }
 
 // NTILE: 32-row output tiles per wave (1: 128-row workgroup blocks, 2: 256-row blocks)
+//
+// The loop runs over STAGES (item, reduction chunk).  The rows of stage q + 1 are requested into registers before the
+// MFMAs of stage q and written to LDS after them: without that, every workgroup of the chip staged, multiplied and
+// stored in lockstep (identical work per item, simultaneous start), HBM saw 32 MB bursts separated by idle gaps and
+// the matrix pipe sat at 53 % (rocprofv3: SQ_WAIT_ANY 36 % with both waves of a SIMD parked together).
 template <bool COLS, int NTILE>
 __global__ __launch_bounds__(kThreads, 2) void lm_gemm(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -111,78 +117,109 @@ __global__ __launch_bounds__(kThreads, 2) void lm_gemm(const GemmArgs a) {
   const int row_blk = blockIdx.y * (128 * NTILE);
   const int items = (a.ncb + kCB - 1) / kCB;
   const int kc_rows = depth < kKC ? depth : kKC;
+  const int nk = (depth + kKC - 1) / kKC;                       // reduction chunks per item
+  const int my_items = items > (int)blockIdx.x ? (items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int nstages = my_items * nk;
 
-  for (int item = blockIdx.x; item < items; item += gridDim.x) {
-    const int cb0 = item * kCB;
-    f32x16 acc[NTILE][kCB];
+  constexpr int kPre = kCB * kKC * 8 / kThreads;  // float4 per thread for one stage (16)
+  f32x4 pre[kPre];
+  auto stage_item = [&](int q) { return (int)blockIdx.x + (q / nk) * (int)gridDim.x; };
+  auto fetch = [&](int q) {
+    const int cb0 = stage_item(q) * kCB, k0 = (q % nk) * kKC;
+    const int kn = depth - k0 < kKC ? depth - k0 : kKC;
+    const int quads = kn * 8;
 #pragma unroll
-    for (int jt = 0; jt < NTILE; ++jt)
+    for (int c = 0; c < kCB; ++c) {
+      // unconditional, clamped loads (see lm_gemm_nt8): a column block past the end re-reads the last one and is never stored
+      const float* src = a.X + ((long long)(cb0 + c < a.ncb ? cb0 + c : a.ncb - 1) * x_rows + k0) * kT;
 #pragma unroll
-      for (int c = 0; c < kCB; ++c)
+      for (int u = 0; u < kPre / kCB; ++u) {
+        int q4 = u * kThreads + L.tid;
+        q4 = q4 < quads ? q4 : quads - 1;
+        pre[c * (kPre / kCB) + u] = *reinterpret_cast<const f32x4*>(src + 4 * q4);
+      }
+    }
+  };
+  auto stash = [&](int q) {
+    const int k0 = (q % nk) * kKC;
+    const int kn = depth - k0 < kKC ? depth - k0 : kKC;
+    const int quads = kn * 8;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[jt][c][r] = 0.0f;
-    for (int k0 = 0; k0 < depth; k0 += kKC) {
-      const int kn = depth - k0 < kKC ? depth - k0 : kKC;  // rows of this chunk (multiple of 32)
-      __syncthreads();  // readers of the previous image are done
-      // stage X[cb0 .. cb0+CB)[k0 .. k0+kn)[32] -> img[c][r][kTP]; 8 float4 per row
-      {
-        const int quads = kn * 8;
+    for (int c = 0; c < kCB; ++c)
 #pragma unroll
-        for (int c = 0; c < kCB; ++c) {
-          const bool ok = cb0 + c < a.ncb;
-          const float* src = a.X + ((long long)(cb0 + c) * x_rows + k0) * kT;
-          for (int q0 = 0; q0 < quads; q0 += 4 * kThreads) {
-            f32x4 v[4];
+      for (int u = 0; u < kPre / kCB; ++u) {
+        const int q4 = u * kThreads + L.tid;
+        if (q4 < quads) *reinterpret_cast<f32x4*>(smem + (c * kc_rows + (q4 >> 3)) * kTP + 4 * (q4 & 7)) = pre[c * (kPre / kCB) + u];
+      }
+  };
+
+  f32x16 acc[NTILE][kCB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int q = q0 + u * kThreads + L.tid;
-              v[u] = (ok && q < quads) ? *reinterpret_cast<const f32x4*>(src + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            }
+  for (int jt = 0; jt < NTILE; ++jt)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int q = q0 + u * kThreads + L.tid;
-              if (q < quads) *reinterpret_cast<f32x4*>(smem + (c * kc_rows + (q >> 3)) * kTP + 4 * (q & 7)) = v[u];
-            }
-          }
+    for (int c = 0; c < kCB; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[jt][c][r] = 0.0f;
+  if (nstages > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int q = 0; q < nstages; ++q) {
+    // vmcnt is an in-order queue: requested BEFORE the MFMAs, the next stage's rows sit in front of every weight
+    // chunk this stage streams (each chunk then waits for them once); requested AFTER, they overlap only the
+    // epilogue stores and the barrier.  Both forms are kept; the engine picks per launch (a.prefetch).
+    if (a.prefetch && q + 1 < nstages) fetch(q + 1);
+    const int k0 = (q % nk) * kKC;
+    const int kn = depth - k0 < kKC ? depth - k0 : kKC;
+#pragma unroll
+    for (int jt = 0; jt < NTILE; ++jt) {
+      const int row0 = row_blk + (L.wave + kWaves * jt) * 32;
+      if (row0 < out_rows) {
+        if constexpr (COLS) {
+          const unsigned lane_off = static_cast<unsigned>(4 * L.lh * a.w_cols + row0 + L.ln) * 4u;
+          gemm_core<true>(acc[jt], a.W + (long long)k0 * a.w_cols, a.w_cols, lane_off, kn >> 5, smem, kc_rows, L);
+        } else {
+          const unsigned lane_off = static_cast<unsigned>((row0 + L.ln) * a.w_cols + 4 * L.lh) * 4u;
+          gemm_core<false>(acc[jt], a.W + k0, a.w_cols, lane_off, kn >> 5, smem, kc_rows, L);
         }
       }
-      __syncthreads();
+    }
+    if (!a.prefetch && q + 1 < nstages) fetch(q + 1);
+    if ((q % nk) == nk - 1) {
+      // epilogue: bias on value-stream blocks, optional adds, 128-byte row segments per half wave
+      const int cb0 = stage_item(q) * kCB;
 #pragma unroll
       for (int jt = 0; jt < NTILE; ++jt) {
         const int row0 = row_blk + (L.wave + kWaves * jt) * 32;
         if (row0 < out_rows) {
-          if constexpr (COLS) {
-            const unsigned lane_off = static_cast<unsigned>(4 * L.lh * a.w_cols + row0 + L.ln) * 4u;
-            gemm_core<true>(acc[jt], a.W + (long long)k0 * a.w_cols, a.w_cols, lane_off, kn >> 5, smem, kc_rows, L);
-          } else {
-            const unsigned lane_off = static_cast<unsigned>((row0 + L.ln) * a.w_cols + 4 * L.lh) * 4u;
-            gemm_core<false>(acc[jt], a.W + k0, a.w_cols, lane_off, kn >> 5, smem, kc_rows, L);
+#pragma unroll
+          for (int c = 0; c < kCB; ++c) {
+            const int cb = cb0 + c;
+            if (cb < a.ncb) {
+              const bool with_bias = !COLS && a.bias && (cb % a.K) == 0;
+              const long long base = ((long long)cb * y_rows + row0) * kT + L.ln;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int rr = acc_row(r, L.lh);
+                float v = acc[jt][c][r];
+                if (with_bias) v += a.bias[row0 + rr];
+                if (a.add0) v += a.add0[base + rr * kT];
+                if (a.add1) v += a.add1[base + rr * kT];
+                a.Y[base + rr * kT] = v;
+              }
+            }
           }
         }
+#pragma unroll
+        for (int c = 0; c < kCB; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[jt][c][r] = 0.0f;
       }
     }
-    // epilogue: bias on value-stream blocks, optional adds, 128-byte row segments per half wave
-#pragma unroll
-    for (int jt = 0; jt < NTILE; ++jt) {
-      const int row0 = row_blk + (L.wave + kWaves * jt) * 32;
-      if (row0 >= out_rows) continue;
-#pragma unroll
-      for (int c = 0; c < kCB; ++c) {
-        const int cb = cb0 + c;
-        if (cb >= a.ncb) continue;
-        const bool with_bias = !COLS && a.bias && (cb % a.K) == 0;
-        const long long base = ((long long)cb * y_rows + row0) * kT + L.ln;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = acc_row(r, L.lh);
-          float v = acc[jt][c][r];
-          if (with_bias) v += a.bias[row0 + rr];
-          if (a.add0) v += a.add0[base + rr * kT];
-          if (a.add1) v += a.add1[base + rr * kT];
-          a.Y[base + rr * kT] = v;
-        }
-      }
-    }
+    __syncthreads();  // every wave has finished reading this stage's image
+    if (q + 1 < nstages) stash(q + 1);
+    __syncthreads();
   }
 }
 
@@ -348,9 +385,12 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_nt8(const GemmNtArgs a) {
     const float* vs = a.V + ((long long)cb * a.v_rows + vc0) * kT;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int q = u * 512 + tid;
-      if (q < zq) pre[u] = *reinterpret_cast<const f32x4*>(zs + 4 * q);
-      else if (q < zq + vq) pre[u] = *reinterpret_cast<const f32x4*>(vs + 4 * (q - zq));
+      // ONE UNCONDITIONAL load per register (address clamped, surplus lanes re-read the last quad): predicated loads
+      // into a register make the compiler drain vmcnt before each of them, which serialises the whole prefetch
+      int q = u * 512 + tid;
+      q = q < zq + vq ? q : zq + vq - 1;
+      const float* src = q < zq ? zs + 4 * q : vs + 4 * (q - zq);
+      pre[u] = *reinterpret_cast<const f32x4*>(src);
     }
   };
   auto stash = [&](float* img) {
