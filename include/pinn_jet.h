@@ -171,6 +171,34 @@ int pinn_residual_backward(const PinnNetDesc* net, const float* const* weights, 
                            const float* residual_cotangent, float* const* weight_grads, void* workspace,
                            size_t ws_bytes, void* stream);
 
+/* ---- training step (pinnrl/training/trainer.py:686-698, pinnrl/pdes/pde_base.py:1101-1165) -------------------------
+ * With these two entry points a whole optimiser step is a handful of launches with no autograd in it (and can be
+ * captured in a HIP graph): pinn_residual_loss_grad for the residual term, pinn_jet_forward / pinn_jet_backward
+ * (orders 0, 0) for the network values on the boundary / initial points, pinn_point_losses for their loss terms,
+ * pinn_adam_clip_step for clip_grad_norm_ + Adam. */
+#define PINN_MAX_POINT_TERMS 8
+
+/* Term k (k < n_terms) covers points [lo[k], hi[k]) of u and has its own target array of hi[k] - lo[k] floats:
+ * term_losses[k] = mean l(u - target_k) with l = PinnLoss `loss` (pde_base.py:309-326), and
+ * cotangent[n] = sum_k weights[k] * l'(u[n] - target_k[n]) / (hi[k] - lo[k])  (n_total floats, overwritten).
+ * lo / hi / targets / weights are HOST arrays (read before the call returns); u, targets[k], outputs: device.
+ * summary4 (nullable, device): {residual, boundary, initial, total} of compute_loss — residual = residual_sum[0] *
+ * residual_scale (the residual launch's loss sum / N), boundary = sum of the first n_boundary_terms term losses,
+ * initial = the rest, total = residual_weight * residual + sum_k weights[k] * term_losses[k]. */
+int pinn_point_losses(const float* u, int32_t n_total, int32_t n_terms, const int32_t* lo, const int32_t* hi,
+                      const float* const* targets, const float* weights, int32_t loss, float huber_delta,
+                      float* term_losses, float* cotangent, const float* residual_sum, float residual_scale,
+                      float residual_weight, int32_t n_boundary_terms, float* summary4, void* stream);
+
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) (skipped when max_norm <= 0) followed by
+ * torch.optim.Adam(lr, (beta1, beta2), eps, weight_decay).step() on ONE flat fp32 buffer of n elements.
+ * lr and step are DEVICE scalars (step = number of steps taken so far, incremented by the call) so that a captured
+ * graph follows a learning-rate schedule; scratch64: 64 floats; grad_norm_out: nullable, receives the norm before
+ * clipping.  The norm is reduced in a fixed order: deterministic. */
+int pinn_adam_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
+                        float beta1, float beta2, float eps, float weight_decay, float max_norm, float* step,
+                        float* scratch64, float* grad_norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,24 @@ __global__ void lm_unpack_kernel(const PackTable tab, const float* packed_grad) 
   }
 }
 
+// deterministic mode: dst_k[f * mul_k + add_k] += sum over workgroups (fixed order) of partial[b][slot_k][f]
+struct SlotReduce {
+  int n;               // destinations
+  float* dst[8];
+  int slot[8], mul[8], add[8], len[8];
+  int row;             // floats per workgroup row of the partial buffer
+};
+__global__ void lm_reduce_slots(const float* partial, int nblocks, SlotReduce r) {
+  for (int k = 0; k < r.n; ++k) {
+    if (!r.dst[k]) continue;
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < r.len[k]; f += gridDim.x * blockDim.x) {
+      float s = 0.0f;
+      for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * r.row + r.slot[k] + f];
+      r.dst[k][f * r.mul[k] + r.add[k]] += s;
+    }
+  }
+}
+
 int failf(char* err, size_t n, int code, const char* fmt, ...) {
   if (err && n) {
     va_list ap;
@@ -338,7 +356,7 @@ struct Layout {
   size_t params = 0, grads = 0, U = 0;
   size_t V[kMaxNodes], Y[kMaxNodes], Vh = 0;
   size_t Zbar[kMaxNodes], Vbar[kMaxNodes], Pbar[kMaxNodes + 1];  // Pbar[m]: skip cotangent produced by node m's prologue (kMaxNodes = head)
-  size_t partial = 0, partial_floats = 0;
+  size_t partial = 0, partial_floats = 0, det = 0;
   size_t total = 0;          // floats
 };
 
@@ -443,7 +461,11 @@ void make_layout(const Program& P, long long N, int K, bool bwd, bool determinis
     }
     L.partial = o;
     L.partial_floats = 0;
+    L.det = o;
     if (deterministic) {
+      L.det = o;
+      o += (size_t)1024 * 7 * 1024;  // per-workgroup partials of the element-wise / head kernels (<= 1024 workgroups)
+      L.partial = o;
       size_t big = 0;
       for (int m = 0; m < P.n_nodes; ++m) {
         const size_t e = (size_t)round32(P.node[m].Hout) * round32(P.node[m].Hin) + round32(P.node[m].Hout);
@@ -677,7 +699,21 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       h.U = ws + L.U;
       h.dw_out = gp(P.w_out);
       h.db_out = gp(P.b_out);
-      LM_CHECK(launch_head(c.nt, c.nx, h, fpt, ew_grid(ct), st));
+      const bool det = c.deterministic && c.bwd;
+      if (det) h.det_partial = ws + L.det;
+      const int hgrid = ew_grid(ct);
+      LM_CHECK(launch_head(c.nt, c.nx, h, fpt, hgrid, st));
+      if (det) {
+        SlotReduce r;
+        memset(&r, 0, sizeof(r));
+        r.row = 1026;
+        r.n = 3;
+        r.dst[0] = h.dw_out; r.slot[0] = 0; r.mul[0] = 1; r.len[0] = h.H;
+        r.dst[1] = (c.mode == MODE_PDE) ? c.loss_sum : nullptr; r.slot[1] = 1024; r.mul[1] = 1; r.len[1] = 1;
+        r.dst[2] = h.db_out; r.slot[2] = 1025; r.mul[2] = 1; r.len[2] = 1;
+        hipLaunchKernelGGL(lm_reduce_slots, dim3(4), dim3(256), 0, st, ws + L.det, hgrid, r);
+        LM_CHECK(hipGetLastError());
+      }
     }
     if (!c.bwd) continue;
     // ---------------- reverse ----------------
@@ -711,8 +747,27 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
         a.d_encb = gp(pro.enc_b);
         if (!a.d_encW && pro.ln_g < 0 && pro.skip_node < 0) return PINN_OK;
       }
-      e = launch_ew(c.nt, c.nx, a, true, pro.act, fpt, ew_grid(ct), st);
+      const bool has_sums = pro.ln_g >= 0 || (pro.src_kind == SRC_COORDS_LINEAR && a.d_encW);
+      if (c.deterministic && has_sums) a.det_partial = ws + L.det;
+      const int egrid = ew_grid(ct);
+      e = launch_ew(c.nt, c.nx, a, true, pro.act, fpt, egrid, st);
       if (e != hipSuccess) return failf(err, en, PINN_ERR_HIP, "HIP error %d: %s (lm_ew_bwd)", (int)e, hipGetErrorString(e));
+      if (a.det_partial) {
+        SlotReduce r;
+        memset(&r, 0, sizeof(r));
+        r.row = 7 * 1024;
+        r.n = 7;
+        r.dst[0] = pro.ln_g >= 0 ? a.d_ln_g : nullptr; r.slot[0] = 0; r.mul[0] = 1;
+        r.dst[1] = pro.ln_g >= 0 ? a.d_ln_b : nullptr; r.slot[1] = 1024; r.mul[1] = 1;
+        for (int cc = 0; cc < 4; ++cc) {
+          r.dst[2 + cc] = a.d_encW; r.slot[2 + cc] = (2 + cc) * 1024; r.mul[2 + cc] = 4; r.add[2 + cc] = cc;
+        }
+        r.dst[6] = a.d_encb; r.slot[6] = 6 * 1024; r.mul[6] = 1;
+        for (int k = 0; k < 7; ++k) r.len[k] = a.H;
+        hipLaunchKernelGGL(lm_reduce_slots, dim3(4), dim3(256), 0, st, ws + L.det, egrid, r);
+        e = hipGetLastError();
+        if (e != hipSuccess) return failf(err, en, PINN_ERR_HIP, "HIP error %d: %s (lm_reduce_slots)", (int)e, hipGetErrorString(e));
+      }
       return PINN_OK;
     };
     if ((rc = run_ew_bwd(P.head, kMaxNodes, nullptr)) != PINN_OK) return rc;

@@ -59,6 +59,7 @@ struct EwArgs {
   float* d_ln_b;
   float* d_encW;        // [Hp][4]
   float* d_encb;
+  float* det_partial;   // deterministic mode: per-workgroup partials [grid][7][1024] instead of float atomics
 };
 
 // Record access: element (row, point n) of this thread's feature group lives at tile_base + row * 32 floats + tid * 4
@@ -564,7 +565,11 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
       }
     }
   }
-  if (LN || enc_grad) {
+  if ((LN || enc_grad) && a.det_partial) {  // plain stores; lm_reduce_slots adds them up in workgroup order
+    __syncthreads();
+    float* P = a.det_partial + (long long)blockIdx.x * (kAcc * 1024);
+    for (int i = tid; i < kAcc * 1024; i += nthreads) P[i] = pacc[i];
+  } else if (LN || enc_grad) {
     __syncthreads();
     for (int f = tid; f < a.H; f += nthreads) {
       if (LN && a.d_ln_g) {

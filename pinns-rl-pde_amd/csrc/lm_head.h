@@ -31,6 +31,7 @@ struct HeadArgs {
   float* U;             // [tile][K][32]
   float* dw_out;        // packed [Hp]
   float* db_out;        // packed [1]
+  float* det_partial;   // deterministic mode: per-workgroup partials [grid][1026] = dw_out (1024) | loss | db_out
 };
 
 template <int NT, int NX, int FPT>
@@ -116,6 +117,18 @@ __global__ __launch_bounds__(1024) void lm_head(const HeadArgs a) {
     }
   }
   __syncthreads();
+  if (a.det_partial) {
+    float* P = a.det_partial + (long long)blockIdx.x * 1026;
+    for (int i = tid; i < 1024; i += nthreads) P[i] = pacc[i];
+    if (g == 0) {
+      const float ls = pt_sum(ploss), ds = pt_sum(pdb);
+      if (n == 0) {
+        P[1024] = ls;
+        P[1025] = ds;
+      }
+    }
+    return;
+  }
   if (a.bwd && a.dw_out)
     for (int f = tid; f < a.H; f += nthreads) atomicAdd(a.dw_out + f, pacc[f]);
   if (g == 0) {  // the 16 lanes of group 0 hold the per-point partials

@@ -302,6 +302,44 @@ def residual_backward(prog: NetProgram, pd, x: Tensor, t: Tensor, res_bar: Tenso
 
 
 # ---------------------------------------------------------------------------------------------
+# training-step kernels (no autograd): point-wise loss terms, clip + Adam over a flat buffer
+# ---------------------------------------------------------------------------------------------
+def point_losses(u: Tensor, terms: Sequence[Tuple[int, int, Tensor, float]], loss: str, huber_delta: float,
+                 term_losses: Tensor, cot: Tensor, residual_sum: Optional[Tensor] = None, residual_scale: float = 0.0,
+                 residual_weight: float = 0.0, n_boundary_terms: int = 0, summary4: Optional[Tensor] = None) -> None:
+    """term k = (lo, hi, target (hi - lo,), weight): term_losses[k] = mean l(u[lo:hi] - target);
+    cot[n] = sum_k weight_k l'(.) / (hi - lo); summary4 = {residual, boundary, initial, total}.  One launch."""
+    lib = _lib.load()
+    dev = _require_device(u, term_losses, cot, *[t[2] for t in terms])
+    n = len(terms)
+    lo = (ctypes.c_int32 * n)(*[int(t[0]) for t in terms])
+    hi = (ctypes.c_int32 * n)(*[int(t[1]) for t in terms])
+    tg = (ctypes.c_void_p * n)(*[t[2].data_ptr() for t in terms])
+    w = (ctypes.c_float * n)(*[float(t[3]) for t in terms])
+    with torch.cuda.device(dev):
+        _lib.check(lib.pinn_point_losses(u.data_ptr(), u.numel(), n, lo, hi, tg, w, _lib.LOSS.get(loss, 0),
+                                         float(huber_delta), term_losses.data_ptr(), cot.data_ptr(),
+                                         residual_sum.data_ptr() if residual_sum is not None else None,
+                                         float(residual_scale), float(residual_weight), int(n_boundary_terms),
+                                         summary4.data_ptr() if summary4 is not None else None, _stream(dev)))
+
+
+def adam_clip_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: Tensor, step: Tensor,
+                   scratch: Tensor, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                   weight_decay: float = 0.0, max_norm: float = 0.0, grad_norm_out: Optional[Tensor] = None) -> None:
+    """clip_grad_norm_(max_norm) + Adam on flat fp32 buffers; `lr` and `step` are device scalars.  Three tiny launches."""
+    lib = _lib.load()
+    dev = _require_device(params, grads, exp_avg, exp_avg_sq, lr, step, scratch)
+    n = params.numel()
+    assert grads.numel() >= n and exp_avg.numel() == n and exp_avg_sq.numel() == n and scratch.numel() >= 64
+    with torch.cuda.device(dev):
+        _lib.check(lib.pinn_adam_clip_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
+                                           lr.data_ptr(), beta1, beta2, eps, weight_decay, max_norm, step.data_ptr(),
+                                           scratch.data_ptr(), grad_norm_out.data_ptr() if grad_norm_out is not None else None,
+                                           _stream(dev)))
+
+
+# ---------------------------------------------------------------------------------------------
 # autograd splices
 # ---------------------------------------------------------------------------------------------
 class JetFunction(torch.autograd.Function):

@@ -496,7 +496,10 @@ class PDEBase:
     def _residual_loss(self, model, x: torch.Tensor, t: torch.Tensor, n_total: Optional[int] = None) -> torch.Tensor:
         """mean_n l(r_n): residual, reduction AND dL/dtheta in one launch when the coefficients are plain numbers."""
         if self._has_trainable_coefficients():
-            return self._apply_loss_fn(self.compute_residual(model, x, t))
+            loss = self._apply_loss_fn(self.compute_residual(model, x, t))
+            if n_total is not None and int(n_total) != x.shape[0]:  # shard of a data-parallel batch: local SUM / global N
+                loss = loss * (float(x.shape[0]) / float(n_total))
+            return loss
         _jets_of(model)
         self._prepare_model(model)
         prog = model.program()

@@ -26,6 +26,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from .. import distributed as _D
+from .. import engine as _E
 
 
 class _EmaLossWeights:
@@ -68,6 +69,15 @@ class PDETrainer:
         self.logger = logging.getLogger(__name__)
         self.process_group = process_group
         self.log_every_step = log_every_step
+        if process_group is not None:
+            # replicas must start from ONE theta_0 and apply identical updates: broadcast rank 0's parameters,
+            # and refuse the modes whose per-rank quantities this path does not reduce
+            if config.training.adaptive_weights.enabled:
+                raise NotImplementedError("data-parallel training supports fixed loss weights only: the EMA weight rules "
+                                          "need every loss component reduced over ranks before the update")
+            _D.broadcast_parameters(self.model, process_group)
+            if hasattr(self.pde, "_trainable_params") and len(self.pde._trainable_params):
+                _D.broadcast_parameters(self.pde._trainable_params, process_group)
         self._initialize_optimizer_and_scheduler()
         self.history = {"train_loss": [], "val_loss": [], "residual_loss": [], "boundary_loss": [], "initial_loss": [],
                         "learning_rate": [], "loss_weights": []}
@@ -146,8 +156,12 @@ class PDETrainer:
         x, t = self.pde.generate_collocation_points(num_points)
         with torch.no_grad():  # forward-only fused kernels; the reference builds (and discards) a graph here
             losses = self.pde.compute_loss(self.model, x.to(self.device), t.to(self.device))
-        return {"total_loss": losses["total"].item(), "residual_loss": losses["residual"].item(),
-                "boundary_loss": losses["boundary"].item(), "initial_loss": losses["initial"].item()}
+        vals = torch.stack([losses[k].detach().reshape(()).float() for k in ("total", "residual", "boundary", "initial")])
+        if self.process_group is not None:  # rank-local random validation points: average, so every rank stops together
+            torch.distributed.all_reduce(vals, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+            vals = vals / torch.distributed.get_world_size(self.process_group)
+        v = vals.tolist()
+        return {"total_loss": v[0], "residual_loss": v[1], "boundary_loss": v[2], "initial_loss": v[3]}
 
     # ---------------------------------------------------------------- one step
     def _sample(self, batch_size: int):
@@ -177,16 +191,39 @@ class PDETrainer:
             return _D.sharded_compute_loss(self.pde, self.model, x, t, self.process_group)
         return self.pde.compute_loss(self.model, x, t)
 
+    def _ensure_dp_buffer(self):
+        """Every parameter's `.grad` becomes a VIEW of one persistent [gradients || 4 scalars] buffer: backward
+        accumulates straight into it and the step's single all-reduce runs on it in place (no cat / copy-back)."""
+        if getattr(self, "_dp_buf", None) is not None:
+            return
+        params = self._collect_optimizable_params()
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        buf = torch.zeros(n + 4, dtype=torch.float32, device=params[0].device)
+        for p, o in zip(params, offs):
+            p.grad = buf[o : o + p.numel()].view_as(p)
+        self._dp_buf, self._dp_n = buf, n
+
     def _sync_grads(self, losses=None):
         """ONE all-reduce of [gradients || residual loss]; the reduced (global) residual replaces the local shard's."""
         if self.process_group is None:
             return
-        scalars = [losses["residual"]] if losses is not None else None
-        red = _D.all_reduce_gradients(self._collect_optimizable_params(), self.process_group, scalars=scalars)
+        red = None
+        if getattr(self, "_dp_buf", None) is not None:
+            buf = self._dp_buf
+            if losses is not None:
+                buf[self._dp_n] = losses["residual"].detach().reshape(())
+            torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+            red = buf[self._dp_n : self._dp_n + 1]
+        else:
+            scalars = [losses["residual"]] if losses is not None else None
+            red = _D.all_reduce_gradients(self._collect_optimizable_params(), self.process_group, scalars=scalars)
         if red is not None and losses is not None:
             world = torch.distributed.get_world_size(self.process_group)
             local = losses["residual"].detach()
-            losses["residual"] = red[0]
+            losses["residual"] = red[0].clone()
             # local total = rw * local_residual + (aux terms) / world  ->  global total (for logging only)
             lw = self.pde._loss_weights() if hasattr(self.pde, "_loss_weights") else None
             rw = (lw.get("pde", lw.get("residual", 1.0)) if lw else 1.0)
@@ -226,7 +263,14 @@ class PDETrainer:
         """zero_grad -> compute_loss -> backward -> clip -> step  (trainer.py:576-694)."""
         if self._is_lbfgs:
             return self._lbfgs_step(x, t)
-        self.optimizer.zero_grad()
+        if getattr(self, "_flat", None) is not None:  # parameters live in the flat buffers: same sequence, not captured
+            self._manual_launches(x, t)
+            return self._manual_losses()
+        if self.process_group is not None:
+            self._ensure_dp_buffer()
+            self._dp_buf.zero_()  # the .grad views stay attached (zero_grad(set_to_none=True) would drop them)
+        else:
+            self.optimizer.zero_grad()
         losses = self._losses(x, t)
         if self.use_adaptive_weights and self.config.training.mode != "data_only":
             losses["total"] = self._adaptive_total(losses)
@@ -238,49 +282,141 @@ class PDETrainer:
         self.optimizer.step()
         return losses
 
-    # ---------------------------------------------------------------- graph-captured step
-    def make_graphed_step(self, batch_size: int, warmup: int = 3):
-        """Capture ONE whole training step — fresh device-side sample, compute_loss, backward, clip_grad_norm_, Adam —
-        in a HIP graph and return `(replay, losses)`: `replay()` runs a step, `losses` is the dict of STATIC loss
-        tensors it refreshes.  Same arithmetic as `train_step` on `_sample(batch_size)`; what it removes is the
-        per-step host work (~60 launch-bound kernels and the Python between them).  Requirements of graph capture:
-        Adam (made capturable: its step counter moves to the device), no adaptive loss weights, no RL/RAR sampling
-        (their control flow is host-side), gradients kept allocated (`zero_grad(set_to_none=False)`), one process,
-        and no autograd graph of an earlier eager step still referenced by the caller (drop old loss tensors first:
-        torch's capture of a backward that meets a stale AccumulateGrad node crashes on this ROCm build)."""
-        if self._is_lbfgs or self.use_adaptive_weights or self.process_group is not None or self.rl_agent is not None:
-            raise NotImplementedError("graph capture covers the single-process Adam step without adaptive loss weights "
-                                      "or RL-driven sampling")
-        if getattr(self.config.training, "collocation_distribution", "uniform") not in ("uniform", "stratified"):
-            raise NotImplementedError("graph capture needs a host-independent sampler (uniform / stratified)")
-        for g in self.optimizer.param_groups:
-            g["capturable"] = True
-        for st in self.optimizer.state.values():  # steps taken eagerly so far: counters move to the device
-            if "step" in st and not st["step"].is_cuda:
-                st["step"] = st["step"].to(self.device)
-        gc = self.config.training.gradient_clipping
+    # ---------------------------------------------------------------- autograd-free step
+    def _manual_step_unsupported(self) -> Optional[str]:
+        """None when the step can run as the fixed launch sequence below; else the reason (callers fall back)."""
+        from ..pdes.pde_base import PDEBase
+
+        tc = self.config.training
+        if self._is_lbfgs or getattr(tc, "optimizer", "adam") != "adam":
+            return "optimizer is not Adam"
+        if self.use_adaptive_weights:
+            return "adaptive loss weights"
+        if self.process_group is not None:
+            return "data-parallel training"
+        if self.rl_agent is not None or getattr(tc, "collocation_distribution", "uniform") not in ("uniform", "stratified"):
+            return "host-driven sampler (RL / residual-based)"
+        if type(self.pde).compute_loss is not PDEBase.compute_loss:
+            return f"{type(self.pde).__name__} overrides compute_loss"
+        if self.pde.dimension != 1 or self.pde._has_trainable_coefficients() or self.pde._training_mode() != "forward":
+            return "multi-dimensional, inverse or data-driven mode"
+        if getattr(self.pde, "observation_data", None):
+            return "observation data term"
+        ic = getattr(self.pde.config, "initial_condition", None) or {}
+        if ic.get("type") == "random":
+            return "random initial condition"
+        return None
+
+    def _build_flat_state(self):
+        """Move the parameters into ONE flat fp32 buffer (each `nn.Parameter` becomes a view of it, same layout as the
+        engine's flat gradient) with flat Adam moments beside it; optimizer state of eager steps taken so far comes along."""
+        if getattr(self, "_flat", None) is not None:
+            return self._flat
+        prog = self.model.program()
+        offs, n = prog.grad_layout()
+        dev = self.device
+        theta = torch.zeros(n, dtype=torch.float32, device=dev)
+        m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+        steps = 0.0
+        with torch.no_grad():
+            for p, o in zip(prog.tensors, offs):
+                if o < 0:
+                    continue
+                view = theta[o : o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                st = self.optimizer.state.get(p, {})
+                if "exp_avg" in st:
+                    m[o : o + p.numel()].view_as(p).copy_(st["exp_avg"])
+                    v[o : o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
+                    steps = float(st["step"])
+                p.data = view
+        g = self.optimizer.param_groups[0]
+        pde = self.pde
+        inp_b, xb, tb, inp_i, xi, ti = pde._boundary_and_initial_points()
+        x_all = torch.cat([xb, xi], 0).contiguous()
+        t_all = torch.cat([tb, ti], 0).contiguous()
+        nb, ni = xb.shape[0], xi.shape[0]
+        lw = pde._loss_weights()
+        if lw:
+            rw, bw, iw = lw.get("pde", lw.get("residual", 1.0)), lw.get("boundary", 10.0), lw.get("initial", 10.0)
+        else:
+            rw, bw, iw = 1.0, 10.0, 10.0
+        terms = [(0, nb, fn(xb, tb).reshape(-1).float().contiguous(), float(bw)) for fn in pde.boundary_conditions.values()]
+        ic_fn = pde.boundary_conditions.get("initial") or pde._create_boundary_condition("initial", pde.config.initial_condition)
+        terms.append((nb, nb + ni, ic_fn(xi, ti).reshape(-1).float().contiguous(), float(iw)))
+        self._flat = {
+            "theta": theta, "m": m, "v": v, "grad": torch.zeros(n + 4, dtype=torch.float32, device=dev),
+            "step": torch.tensor([steps], dtype=torch.float32, device=dev),
+            "lr": torch.tensor([g["lr"]], dtype=torch.float32, device=dev),
+            "scratch": torch.zeros(64, dtype=torch.float32, device=dev), "n": n,
+            "x_all": x_all, "t_all": t_all, "terms": terms, "n_bc": len(terms) - 1, "rw": float(rw),
+            "term_losses": torch.zeros(len(terms), dtype=torch.float32, device=dev),
+            "cot": torch.zeros(1, nb + ni, dtype=torch.float32, device=dev),
+            "summary": torch.zeros(4, dtype=torch.float32, device=dev),
+            "betas": g["betas"], "eps": g["eps"], "wd": g["weight_decay"],
+        }
+        return self._flat
+
+    def _manual_launches(self, x, t):
+        """One optimiser step as a fixed launch sequence, no autograd (pinnrl/training/trainer.py:686-698 with
+        pinnrl/pdes/pde_base.py:1086-1235 inlined): zero the flat gradient; residual + mean l(r) + d/dtheta in one
+        launch; network values on the 200 boundary + 100 initial points; their loss terms and cotangents; their
+        reverse sweep into the same flat gradient; clip_grad_norm_ + Adam over the flat buffers."""
+        F = self._flat
+        prog = self.model.program()
+        pd = self.pde._pde_desc()
+        n, N = F["n"], x.shape[0]
+        F["grad"].zero_()
+        _E.residual_loss_grad(prog, pd, x, t, F["rw"] / float(N), F["grad"][:n], loss_sum=F["grad"][n : n + 1])
+        u = _E.jets_forward(prog, F["x_all"], F["t_all"], 0, 0)
+        _E.point_losses(u[0], F["terms"], self.pde._loss_function_name(), self.pde._huber_delta(), F["term_losses"],
+                        F["cot"][0], residual_sum=F["grad"][n : n + 1], residual_scale=1.0 / float(N), residual_weight=F["rw"],
+                        n_boundary_terms=F["n_bc"], summary4=F["summary"])
+        _E.jets_backward(prog, F["x_all"], F["t_all"], 0, 0, F["cot"], F["grad"][:n])
+        _E.adam_clip_step(F["theta"], F["grad"], F["m"], F["v"], F["lr"], F["step"], F["scratch"], beta1=F["betas"][0],
+                          beta2=F["betas"][1], eps=F["eps"], weight_decay=F["wd"],
+                          max_norm=float(self.config.training.gradient_clipping))
+
+    def _manual_losses(self):
+        s = self._flat["summary"]
+        return {"residual": s[0], "boundary": s[1], "initial": s[2], "total": s[3]}
+
+    def make_graphed_step(self, batch_size: int, warmup: int = 2):
+        """Capture ONE whole training step in a HIP graph and return `(replay, losses)`: `replay()` runs a step on a
+        fresh device-side sample, `losses` is the dict of STATIC loss tensors it refreshes.
+
+        The captured step contains no autograd at all: it is `_manual_launches` — six kernels of this library plus the
+        sampler's handful of element-wise ones — writing into persistent flat buffers (parameters, gradient, Adam
+        moments; the parameters of the model become views of the flat buffer).  Nothing in it depends on autograd
+        nodes of earlier eager steps, so it is safe to call after any number of `train_step`s (round 1's capture of
+        `loss.backward()` crashed on a stale AccumulateGrad node).  The learning rate lives in a device scalar that
+        `train` refreshes after each scheduler step.  Steps the fixed sequence does not cover (L-BFGS, adaptive
+        weights, RL / residual-based sampling, data-parallel, PDEs with their own compute_loss) raise."""
+        why = self._manual_step_unsupported()
+        if why is not None:
+            raise NotImplementedError(f"graph capture covers the plain Adam step only ({why})")
+        self._build_flat_state()
 
         def step():
             x, t = self._sample(batch_size)
-            self.optimizer.zero_grad(set_to_none=False)
-            losses = self._losses(x, t)
-            losses["total"].backward()
-            if gc > 0:
-                nn.utils.clip_grad_norm_(self.model.parameters(), gc)
-            self.optimizer.step()
-            return losses
+            self._manual_launches(x, t)
 
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):  # allocates gradients / optimizer state before capture
+            for _ in range(max(warmup, 1)):  # sizes the engine's scratch and the allocator pools before capture
                 step()
         torch.cuda.current_stream(self.device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            losses = step()
+            step()
         self._step_graph = graph  # keeps the captured allocations alive
-        return graph.replay, {k: v.detach() for k, v in losses.items()}
+        return graph.replay, self._manual_losses()
+
+    def set_learning_rate(self, lr: float) -> None:
+        """Propagate a scheduler's learning rate to the device scalar the captured / manual step reads."""
+        if getattr(self, "_flat", None) is not None:
+            self._flat["lr"].fill_(float(lr))
 
     # ---------------------------------------------------------------- the loop (trainer.py:391-964)
     def train(self, num_epochs: int, batch_size: int, num_points: int, experiment_dir: str = None):
@@ -304,6 +440,7 @@ class PDETrainer:
             avg = float(torch.stack(step_losses).mean().item())  # ZeroDivisionError upstream when there are no steps
             self._update_scheduler(avg)
             lr = self.optimizer.param_groups[0]["lr"]
+            self.set_learning_rate(lr)
             row = {"train_loss": avg, "residual_loss": float(losses["residual"]), "boundary_loss": float(losses["boundary"]),
                    "initial_loss": float(losses["initial"]), "learning_rate": lr}
             if "data" in losses:
