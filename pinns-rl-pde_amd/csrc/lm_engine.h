@@ -43,15 +43,9 @@ size_t lm_workspace_bytes(const PinnNetDesc* d, long long N, int nt, int nx, boo
 int lm_run(const CallArgs& c, char* err, size_t errlen);
 
 // per-stream-set translation units (lm_inst.hip); `act` = PinnAct, -1 = none, -2 = Fourier features (forward only)
-#ifndef PINN_HOST_ONLY
 #define PINN_LM_DECL(nt, nx)                                                                              \
   hipError_t launch_lm_ew_##nt##_##nx(const EwArgs&, bool bwd, int act, int fpt, int grid, hipStream_t); \
   hipError_t launch_lm_head_##nt##_##nx(const HeadArgs&, int fpt, int grid, hipStream_t);
-#else /* host-only sanitizer build: no kernels are linked */
-#define PINN_LM_DECL(nt, nx)                                                                                               \
-  inline hipError_t launch_lm_ew_##nt##_##nx(const EwArgs&, bool, int, int, int, hipStream_t) { return hipErrorInvalidValue; } \
-  inline hipError_t launch_lm_head_##nt##_##nx(const HeadArgs&, int, int, hipStream_t) { return hipErrorInvalidValue; }
-#endif
 PINN_LM_DECL(0, 0)
 PINN_LM_DECL(1, 0)
 PINN_LM_DECL(1, 1)

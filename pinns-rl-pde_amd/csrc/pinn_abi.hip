@@ -18,12 +18,7 @@
 #include "lm_engine.h"
 
 namespace pinn {
-#ifndef PINN_HOST_ONLY
 #define PINN_DECL(nt, nx) hipError_t launch_jetw_##nt##_##nx(const KernelArgs&, bool, int, hipStream_t);
-#else /* host-only sanitizer build (make asan): descriptor / sizing logic only, no kernels linked */
-#define PINN_DECL(nt, nx) \
-  static hipError_t launch_jetw_##nt##_##nx(const KernelArgs&, bool, int, hipStream_t) { return hipErrorInvalidValue; }
-#endif
 PINN_DECL(0, 0)
 PINN_DECL(1, 0)
 PINN_DECL(1, 1)
@@ -279,13 +274,9 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
   c.bwd = bwd;
   c.deterministic = (net->flags & PINN_FLAG_DETERMINISTIC) != 0;
   c.stream = static_cast<hipStream_t>(stream);
-#ifndef PINN_HOST_ONLY
   rc = lm::lm_run(c, lerr, sizeof(lerr));
   if (rc) return fail(rc, "%s", lerr);
   return PINN_OK;
-#else
-  return fail(PINN_ERR_HIP, "host-only build: no kernels");
-#endif
 }
 
 }  // namespace pinn

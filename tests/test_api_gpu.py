@@ -335,3 +335,28 @@ def test_deterministic_flag_gives_bit_identical_gradients(dev):
         for flat, s_ in runs[1:]:
             assert torch.equal(flat, runs[0][0]) and torch.equal(s_, runs[0][1]), tag
         assert rel_l2(runs[0][0].cpu(), ref.cpu()) <= 1e-5 and abs(float(runs[0][1]) - float(s_ref)) <= 1e-5 * abs(float(s_ref))
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_multi_rank_rehearsal(scaling, dev):
+    """bench.py's N > 1 code path on ONE GPU (PINN_BENCH_REHEARSAL: two ranks on cuda:0 over gloo): weak scaling
+    (own batch per rank) and strong scaling (one global batch split by shard_bounds, north_star's 8-GPU mode)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PINN_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--scaling", scaling, "--points", "20000"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0
+    n = 19881  # 141^2
+    assert out["config"]["global_points"] == (n if scaling == "strong" else 2 * n)
+    assert out["config"]["points_per_gpu"] == (n - n // 2 if scaling == "strong" else n)
+    assert "all-reduce" in out["config"]["collective"]

@@ -36,7 +36,8 @@ class OracleBurgers(P.BurgersEquation):
 
     def _residual_loss(self, model, x, t, n_total=None):
         spec = O.PdeSpec(name="burgers", parameters={"nu": float(self.nu)})
-        r = O.compute_residual(spec, model, x, t)
+        with torch.enable_grad():  # the stand-in differentiates w.r.t. the inputs even under the trainer's no_grad validation
+            r = O.compute_residual(spec, model, x, t)
         n = n_total if n_total is not None else x.shape[0]
         return (r**2).sum() / n
 
@@ -106,3 +107,102 @@ def test_shard_bounds_partition():
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PDETrainer under a process group: broadcast at construction, zero-copy gradient buffer, lock-step
+# replicas, validation loss reduced before the early-stopping decision, unsupported modes refused
+# ---------------------------------------------------------------------------------------------------------------------
+def _trainer_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from pinnrl_amd.config import Config, TrainingConfig
+    from pinnrl_amd.training import PDETrainer
+
+    spec, pde_s, sd, a, m = load_case("burgers_fourier_3x32")
+    torch.manual_seed(200 + rank)  # replicas start DIFFERENT: the trainer itself must broadcast
+    model = OracleModel(spec, {k: v + 0.01 * torch.randn_like(v) for k, v in sd.items()})
+    cfg = Config.__new__(Config)
+    cfg.device = torch.device("cpu")
+    cfg.training = TrainingConfig(learning_rate=1e-3, gradient_clipping=1.0)
+    tr = PDETrainer(model, _pde(), {}, cfg, device=torch.device("cpu"), process_group=dist.group.WORLD)
+    theta0 = torch.cat([p.detach().flatten() for p in model.parameters()])
+    x, t = torch.from_numpy(a["x"])[:101], torch.from_numpy(a["t"])[:101]
+    losses = None
+    for _ in range(2):
+        losses = tr.train_step(x, t)
+    theta2 = torch.cat([p.detach().flatten() for p in model.parameters()])
+    views = all(p.grad is not None and p.grad.untyped_storage().data_ptr() == tr._dp_buf.untyped_storage().data_ptr()
+                for p in model.parameters() if p.requires_grad)
+    torch.manual_seed(300 + rank)  # rank-local validation points
+    val = tr._compute_validation_loss(100)
+    refused = False
+    cfg2 = Config.__new__(Config)
+    cfg2.device = torch.device("cpu")
+    cfg2.training = TrainingConfig()
+    cfg2.training.adaptive_weights.enabled = True
+    try:
+        PDETrainer(OracleModel(spec, sd), _pde(), {}, cfg2, device=torch.device("cpu"), process_group=dist.group.WORLD)
+    except NotImplementedError:
+        refused = True
+    # numpy arrays travel by value (tensors would travel as shared-memory handles that die with this process)
+    out.put((rank, theta0.numpy(), theta2.numpy(), float(losses["residual"]), float(losses["total"]), views, val["total_loss"], refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_under_a_process_group():
+    world, port = 2, 29733 + os.getpid() % 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda z: z[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, a0, a2, ra, ta, va, vla, refa), (_, b0, b2, rb, tb, vb, vlb, refb) = res
+    a0, a2, b0, b2 = (torch.from_numpy(v) for v in (a0, a2, b0, b2))
+    assert torch.equal(a0, b0), "PDETrainer(process_group=...) must broadcast rank 0's parameters"
+    assert torch.equal(a2, b2), "replicas must stay identical after optimizer steps"
+    assert not torch.equal(a0, a2)
+    assert ra == rb and ta == tb, "the reduced (global) residual and total are the same on every rank"
+    assert va and vb, "gradients are views of the single all-reduce buffer (no cat / copy-back)"
+    assert vla == vlb, "the validation loss feeding early stopping is reduced over ranks"
+    assert refa and refb, "adaptive loss weights are refused under data parallelism"
+    # the two data-parallel steps equal two single-process full-batch steps from the same theta_0
+    from pinnrl_amd.config import Config, TrainingConfig
+    from pinnrl_amd.training import PDETrainer
+
+    spec, pde_s, sd, a, m = load_case("burgers_fourier_3x32")
+    model = OracleModel(spec, sd)
+    with torch.no_grad():
+        off = 0
+        for p in model.parameters():
+            p.copy_(a0[off : off + p.numel()].view_as(p))
+            off += p.numel()
+    cfg = Config.__new__(Config)
+    cfg.device = torch.device("cpu")
+    cfg.training = TrainingConfig(learning_rate=1e-3, gradient_clipping=1.0)
+    tr = PDETrainer(model, _pde(), {}, cfg, device=torch.device("cpu"))
+    x, t = torch.from_numpy(a["x"])[:101], torch.from_numpy(a["t"])[:101]
+    for _ in range(2):
+        single = tr.train_step(x, t)
+    want = torch.cat([p.detach().flatten() for p in model.parameters()])
+    assert rel_l2(a2, want) < 1e-5
+    assert abs(ta - float(single["total"])) <= 1e-5 * abs(float(single["total"]))
+
+
+def test_inverse_mode_shard_uses_the_global_count():
+    """A shard's residual loss with a trainable coefficient is its local SUM over the global N."""
+    pde = P.BurgersEquation(P.PDEConfig(name="b", domain=[(-1.0, 1.0)], time_domain=(0.0, 1.0), parameters={"nu": 0.01},
+                                        boundary_conditions={}, initial_condition={"type": "sine"}, exact_solution={},
+                                        device=torch.device("cpu"), trainable_parameters=["nu"]))
+    r = torch.linspace(-1, 1, 30).reshape(-1, 1)
+    pde.compute_residual = lambda model, x, t: r[: x.shape[0]]
+    x = torch.zeros(10, 1)
+    full = pde._residual_loss(None, torch.zeros(30, 1), torch.zeros(30, 1))
+    part = pde._residual_loss(None, x, x, n_total=30)
+    assert torch.allclose(part, (r[:10] ** 2).sum() / 30) and torch.allclose(full, (r**2).mean())
