@@ -274,7 +274,8 @@ def test_lbfgs_and_adam_then_lbfgs_paths(kind, dev):
     from pinnrl_amd.training import PDETrainer
 
     cfg, model, pde, (spec, ps, sd, a, m) = build("burgers_fourier_3x32", dev)
-    cfg.training = TrainingConfig(num_epochs=4, learning_rate=0.5, gradient_clipping=0.0, optimizer=kind)
+    # one learning rate serves both optimisers upstream (trainer.py:292-309): 0.5 suits L-BFGS, Adam wants it small
+    cfg.training = TrainingConfig(num_epochs=4, learning_rate=0.5 if kind == "lbfgs" else 0.01, gradient_clipping=0.0, optimizer=kind)
     cfg.training.lbfgs.max_iter, cfg.training.lbfgs.history_size = 4, 10
     cfg.training.adam_lbfgs_switch_ratio = 0.5
     tr = PDETrainer(model, pde, {}, cfg, device=dev, validation_frequency=100)
