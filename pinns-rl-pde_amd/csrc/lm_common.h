@@ -29,7 +29,7 @@ namespace pinn {
 namespace lm {
 
 constexpr int kMaxNodes = 40;   // GEMM nodes of one network (attention: 4 per layer)
-constexpr int kMaxPack = 144;   // tensors in one pack / unpack launch (state_dict entries + one transposed copy per GEMM weight)
+constexpr int kMaxPack = 184;   // tensors in one pack / unpack launch (state_dict entries + one transposed copy per GEMM weight)
 
 __host__ __device__ inline int round32(int v) { return (v + 31) & ~31; }
 
@@ -45,13 +45,23 @@ struct PackItem {
   int rows, cols;    // logical shape
   int cols_p;        // padded row length (rows_p is implied by the next offset)
   int rows_p;
-  int transpose;     // 1: packed[c][r] = src[r][c]  (Fourier B is (din, M); packed as [M][4])
+  int transpose;     // 0: packed[r][c] = src[r][c];  1: packed[c][r] = src[r][c] (Fourier B (din, M) -> [M][4]);
+                     // 2 / 3: MFMA A-fragment order of src / of src^T (see frag_index): what lm_gemm streams
 };
 
 struct PackTable {
   int n;
   PackItem item[kMaxPack];
 };
+
+// MFMA A-operand ("fragment") order of a padded (R_p x C_p) matrix: the 16 bytes lane (ln, lh) of a wave needs for
+// row tile rt, 32-deep reduction chunk ch, group g — A[32 rt + ln][32 ch + 8 g + 4 lh + 0..3] — are stored at
+// ((((rt * nch + ch) * 4 + g) * 64 + 32 lh + ln) * 4 floats, so one wave-instruction reads 1 KB of CONTIGUOUS memory
+// (8 cache lines, all bytes used) instead of 32 bytes from each of 32 rows (32 lines, a quarter of each used).
+__host__ __device__ inline long long frag_index(int r, int c, int nch) {
+  const int rt = r >> 5, ln = r & 31, ch = c >> 5, g = (c & 31) >> 3, lh = (c & 7) >> 2, i = c & 3;
+  return ((((long long)(rt * nch + ch) * 4 + g) * 64 + lh * 32 + ln) * 4 + i);
+}
 
 }  // namespace lm
 }  // namespace pinn

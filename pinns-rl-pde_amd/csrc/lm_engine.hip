@@ -24,12 +24,14 @@ __global__ void lm_pack_kernel(const PackTable tab, float* packed) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int r = i / it.cols_p, c = i - r * it.cols_p;
     float v = 0.0f;
-    if (it.transpose) {
+    long long dst = i;
+    if (it.transpose == 1 || it.transpose == 3) {
       if (c < it.rows && r < it.cols) v = it.src[c * it.cols + r];
     } else {
       if (r < it.rows && c < it.cols) v = it.src[r * it.cols + c];
     }
-    packed[it.off + i] = v;
+    if (it.transpose >= 2) dst = frag_index(r, c, it.cols_p >> 5);
+    packed[it.off + dst] = v;
   }
 }
 
@@ -175,7 +177,7 @@ int build_program(const PinnNetDesc* d, Program& P, char* err, size_t en) {
   P.din = d->input_dim;
   P.n_tensors = expected_tensors(d);
   if (P.n_tensors < 0) return failf(err, en, PINN_ERR_UNSUPPORTED, "architecture id %d has no kernel", d->arch);
-  if (P.n_tensors + kMaxNodes > kMaxPack) return failf(err, en, PINN_ERR_UNSUPPORTED, "%d tensors exceed the pack table (%d)", P.n_tensors, kMaxPack - kMaxNodes);
+  if (P.n_tensors + 2 * kMaxNodes > kMaxPack) return failf(err, en, PINN_ERR_UNSUPPORTED, "%d tensors exceed the pack table (%d)", P.n_tensors, kMaxPack - 2 * kMaxNodes);
   P.ln_eps = d->ln_eps > 0.0f ? d->ln_eps : 1e-5f;
   const int act = d->arch == PINN_ARCH_SIREN ? PINN_ACT_SIN : d->activation;
   const float par = act_param_of(act, d->act_param);
@@ -391,18 +393,20 @@ void make_layout(const Program& P, long long N, int K, bool bwd, bool determinis
   // a transposed copy of every GEMM weight: Vbar = W^T Zbar then runs as the rows form too (16-byte loads along the
   // reduction axis instead of 16 dword loads per 32-deep chunk: 154 -> 116 us per launch at width 256)
   for (int m = 0; m < P.n_nodes; ++m) {
-    PackItem& it = L.tab.item[P.n_tensors + m];
-    it.src = nullptr;
-    it.user_grad = nullptr;
-    it.off = (unsigned)off;
-    it.rows = P.node[m].Hout;
-    it.cols = P.node[m].Hin;
-    it.transpose = 1;
-    it.rows_p = round32(P.node[m].Hin);
-    it.cols_p = round32(P.node[m].Hout);
-    off += (size_t)it.rows_p * it.cols_p;
+    for (int tr = 0; tr < 2; ++tr) {  // [0]: W in fragment order (forward GEMM), [1]: W^T in fragment order (reverse GEMM)
+      PackItem& it = L.tab.item[P.n_tensors + 2 * m + tr];
+      it.src = nullptr;
+      it.user_grad = nullptr;
+      it.off = (unsigned)off;
+      it.rows = P.node[m].Hout;
+      it.cols = P.node[m].Hin;
+      it.transpose = 2 + tr;
+      it.rows_p = round32(tr ? P.node[m].Hin : P.node[m].Hout);
+      it.cols_p = round32(tr ? P.node[m].Hout : P.node[m].Hin);
+      off += (size_t)it.rows_p * it.cols_p;
+    }
   }
-  L.tab.n = P.n_tensors + P.n_nodes;
+  L.tab.n = P.n_tensors + 2 * P.n_nodes;
   L.n_packed = off;
   // chunk size: the widest record of a chunk stays near the target
   int hmax = P.head.H;
@@ -594,7 +598,10 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
     L.tab.item[i].src = c.weights[i];
     L.tab.item[i].user_grad = (c.bwd && c.grads && !P.transpose[i]) ? c.grads[i] : nullptr;
   }
-  for (int m = 0; m < P.n_nodes; ++m) L.tab.item[P.n_tensors + m].src = c.bwd ? c.weights[P.node[m].w] : nullptr;
+  for (int m = 0; m < P.n_nodes; ++m) {
+    L.tab.item[P.n_tensors + 2 * m].src = c.weights[P.node[m].w];
+    L.tab.item[P.n_tensors + 2 * m + 1].src = c.bwd ? c.weights[P.node[m].w] : nullptr;
+  }
   float* params = ws + L.params;
   float* grads = ws + L.grads;
   hipLaunchKernelGGL(lm_pack_kernel, dim3(8, L.tab.n), dim3(256), 0, st, L.tab, params);
@@ -655,7 +662,7 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       }
       GemmArgs g;
       memset(&g, 0, sizeof(g));
-      g.W = pp(nd.w);
+      g.W = params + L.tab.item[P.n_tensors + 2 * m].off;  // W in fragment order
       g.bias = pp(nd.b);
       g.X = ws + L.V[m];
       g.Y = ws + L.Y[m];
@@ -817,7 +824,7 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       if (pro.src_kind == SRC_COORDS_LINEAR && !gp(pro.enc_w) && !gp(pro.enc_b) && pro.ln_g < 0 && pro.skip_node < 0) continue;
       GemmArgs g;
       memset(&g, 0, sizeof(g));
-      g.W = params + L.tab.item[P.n_tensors + m].off;  // W^T, packed (Hin_p x Hout_p)
+      g.W = params + L.tab.item[P.n_tensors + 2 * m + 1].off;  // W^T in fragment order (Hin_p x Hout_p)
       g.X = zbar;
       g.Y = ws + L.Vbar[m];
       g.add0 = extra[m][0];

@@ -24,7 +24,7 @@ constexpr int kCB = 2;     // column blocks per staged image
 constexpr int kKC = 256;   // reduction rows per staged chunk
 
 struct GemmArgs {
-  const float* W;     // packed weight, (w_rows x w_cols), row stride w_cols
+  const float* W;     // packed weight (w_rows x w_cols) in MFMA fragment order (lm_common.h::frag_index)
   const float* bias;  // rows form: w_rows floats or null
   const float* X;     // input record: ncb blocks of (x_rows x 32)
   float* Y;           // output record: ncb blocks of (y_rows x 32)
@@ -40,10 +40,11 @@ struct WFrag16 {
   f32x4 g[4];
 };
 
+// W: this wave's row tile in fragment order (1 KB per (chunk, group)); lane_off = 16 * lane
 __device__ __forceinline__ void ld_rows(WFrag16& w, const float* W, unsigned lane_off, int ch) {
-  const char* base = reinterpret_cast<const char*>(W + 32 * ch);
+  const char* base = reinterpret_cast<const char*>(W + 1024 * ch);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) w.g[g] = *reinterpret_cast<const f32x4*>(base + lane_off + 32u * g);
+  for (int g = 0; g < 4; ++g) w.g[g] = *reinterpret_cast<const f32x4*>(base + lane_off + 1024u * g);
 }
 
 __device__ __forceinline__ void ld_cols(WFrag16& w, const float* W, int ld, unsigned lane_off, int ch) {
@@ -180,8 +181,9 @@ __global__ __launch_bounds__(kThreads, 2) void lm_gemm(const GemmArgs a) {
           const unsigned lane_off = static_cast<unsigned>(4 * L.lh * a.w_cols + row0 + L.ln) * 4u;
           gemm_core<true>(acc[jt], a.W + (long long)k0 * a.w_cols, a.w_cols, lane_off, kn >> 5, smem, kc_rows, L);
         } else {
-          const unsigned lane_off = static_cast<unsigned>((row0 + L.ln) * a.w_cols + 4 * L.lh) * 4u;
-          gemm_core<false>(acc[jt], a.W + k0, a.w_cols, lane_off, kn >> 5, smem, kc_rows, L);
+          const unsigned lane_off = static_cast<unsigned>(L.tid & 63) * 16u;
+          const float* wt = a.W + ((long long)(row0 >> 5) * (a.w_cols >> 5) + (k0 >> 5)) * 1024;  // row tile, first chunk of this stage
+          gemm_core<false>(acc[jt], wt, a.w_cols, lane_off, kn >> 5, smem, kc_rows, L);
         }
       }
     }
