@@ -640,8 +640,8 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
     a.skip = pro.skip_node >= 0 ? ws + L.V[pro.skip_node] : nullptr;
     return fpt;
   };
-  auto ew_grid = [&](long long ct) {
-    long long g = 2LL * ct;
+  auto ew_grid = [&](long long ct) {  // one workgroup per tile (both of its 16-point halves), two workgroups per CU
+    long long g = ct;
     const long long cap = 2LL * cus;
     return (int)(g < cap ? g : cap);
   };

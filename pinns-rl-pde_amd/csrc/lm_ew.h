@@ -385,7 +385,11 @@ __global__ __launch_bounds__(1024) void lm_fourier_fwd(const EwArgs a) {
   constexpr int K = 1 + NT + NX;
   const int tid = threadIdx.x, n = tid & (kPT - 1), g = tid >> 4;
   const unsigned voff = static_cast<unsigned>(g * kT + n) * 4u;
-  for (long long unit = blockIdx.x; unit < 2 * a.ntiles; unit += gridDim.x) {
+  for (long long uu = 2LL * blockIdx.x; uu < 2 * a.ntiles; uu += (uu & 1) ? 2LL * gridDim.x - 1 : 1) {
+    // both 16-point halves of a tile back to back in the SAME workgroup: a 128-byte record row is then fetched from HBM
+    // once (the second half hits this CU's caches) and its two 64-byte stores merge; with the halves on neighbouring
+    // workgroups (different XCDs under round-robin dispatch) every line crossed the fabric twice
+    const long long unit = uu;
     float xin[4];
     bool ok;
     load_coords(a, unit, n, xin, ok);
@@ -437,7 +441,11 @@ __global__ __launch_bounds__(1024) void lm_ew_fwd(const EwArgs a) {
   bool valid[FPT];
 #pragma unroll
   for (int i = 0; i < FPT; ++i) valid[i] = g + a.G * i < a.H;
-  for (long long unit = blockIdx.x; unit < 2 * a.ntiles; unit += gridDim.x) {
+  for (long long uu = 2LL * blockIdx.x; uu < 2 * a.ntiles; uu += (uu & 1) ? 2LL * gridDim.x - 1 : 1) {
+    // both 16-point halves of a tile back to back in the SAME workgroup: a 128-byte record row is then fetched from HBM
+    // once (the second half hits this CU's caches) and its two 64-byte stores merge; with the halves on neighbouring
+    // workgroups (different XCDs under round-robin dispatch) every line crossed the fabric twice
+    const long long unit = uu;
     float xin[4];
     bool ok;
     load_coords(a, unit, n, xin, ok);
@@ -483,7 +491,11 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
     for (int i = tid; i < kAcc * 1024; i += nthreads) pacc[i] = 0.0f;
     __syncthreads();
   }
-  for (long long unit = blockIdx.x; unit < 2 * a.ntiles; unit += gridDim.x) {
+  for (long long uu = 2LL * blockIdx.x; uu < 2 * a.ntiles; uu += (uu & 1) ? 2LL * gridDim.x - 1 : 1) {
+    // both 16-point halves of a tile back to back in the SAME workgroup: a 128-byte record row is then fetched from HBM
+    // once (the second half hits this CU's caches) and its two 64-byte stores merge; with the halves on neighbouring
+    // workgroups (different XCDs under round-robin dispatch) every line crossed the fabric twice
+    const long long unit = uu;
     float xin[4];
     bool ok;
     load_coords(a, unit, n, xin, ok);

@@ -51,7 +51,11 @@ __global__ __launch_bounds__(1024) void lm_head(const HeadArgs a) {
   for (int i = 0; i < FPT; ++i) w[i] = vec_ld(a.w_out, a.G * i, goff);  // zero on padding features
   const float b0 = a.b_out[0];
   float ploss = 0.0f, pdb = 0.0f;
-  for (long long unit = blockIdx.x; unit < 2 * a.ntiles; unit += gridDim.x) {
+  for (long long uu = 2LL * blockIdx.x; uu < 2 * a.ntiles; uu += (uu & 1) ? 2LL * gridDim.x - 1 : 1) {
+    // both 16-point halves of a tile back to back in the SAME workgroup: a 128-byte record row is then fetched from HBM
+    // once (the second half hits this CU's caches) and its two 64-byte stores merge; with the halves on neighbouring
+    // workgroups (different XCDs under round-robin dispatch) every line crossed the fabric twice
+    const long long unit = uu;
     const long long p = a.p_base + unit * kPT + n;
     const bool ok = p < a.N;
     const long long rec_off = (unit >> 1) * (long long)K * a.Hp * kT + (unit & 1) * kPT;
