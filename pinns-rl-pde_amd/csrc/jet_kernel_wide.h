@@ -1,7 +1,7 @@
 // "Wide" variant of the fused jet kernel: ALL K streams of a tile are resident in LDS at once.
 //
 // Used when K * HMAX * 36 * 4 B (twice that with the reverse sweep) fits the 160 KB LDS of a CU — e.g. the
-// headline Burgers / fourier 4x128 workload (K = 4).  Compared with the stream-serial kernel (jet_kernel.h),
+// headline Burgers / fourier 4x128 workload (K = 4).  Compared with a stream-serial staging (one stream in LDS at a time),
 // which scales to any K and to width 256, this layout
 //   * reuses every weight element for all K streams of a k-step (one A operand, K MFMAs) and streams the weight
 //     operand from L2 in 32-k chunks one chunk ahead of its MFMAs (16 VGPRs in flight instead of a 64-VGPR fragment),
@@ -15,7 +15,7 @@
 //     whose tape record is parked in LDS (inside the wave's own rows of the idle a_{l-1} image) instead of the slab,
 //   * has a compile-time image height (HMAX) so that every LDS access is base register + immediate offset, and
 //     pins each GEMM's operand prefetch one group ahead of its MFMAs with sched_barrier.
-// Same arithmetic, same tape layout and argument structures as jet_kernel.h; tests run both variants.
+// Shared descriptors, accumulator layout and tape words: jet_kernel.h; the layer-major engine (lm_*.h) computes the same arithmetic and tests run both.
 #pragma once
 #include "jet_kernel.h"
 

@@ -157,10 +157,16 @@ static bool stream_set_compiled(int nt, int nx) {
 }
 
 static hipError_t dispatch_wide(int nt, int nx, const KernelArgs& a, bool bwd, int grid, hipStream_t st) {
-#define PINN_CASE(NT_, NX_) \
+#define PINN_CASE2(NT_, NX_) \
   if (nt == NT_ && nx == NX_) return launch_jetw_##NT_##_##NX_(a, bwd, grid, st);
+#define PINN_CASE(NT_, NX_) PINN_CASE2(NT_, NX_)
+#ifdef PINN_DEV /* make dev: one stream set */
+  PINN_CASE(PINN_DEV_NT, PINN_DEV_NX)
+#else
   PINN_CASE(0, 0) PINN_CASE(1, 0) PINN_CASE(1, 1) PINN_CASE(1, 2) PINN_CASE(1, 3) PINN_CASE(1, 4) PINN_CASE(2, 0) PINN_CASE(2, 2)
+#endif
 #undef PINN_CASE
+#undef PINN_CASE2
   return hipErrorInvalidValue;
 }
 

@@ -4,6 +4,8 @@ Tolerance: <= 1e-5 relative L2 against the reference's fp32 outputs AND against 
 (north_star's bar); fp32 end to end, no reduced precision anywhere.
 """
 
+import re
+
 import pytest
 import torch
 
@@ -125,9 +127,37 @@ def test_build_info_and_fallback_units(dev):
     still has to meet the parity bar (run one of them: wave needs stream set (2, 2))."""
     from pinnrl_amd import _lib
 
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import engine as E
+    import oracle as O
+
     info = _lib.build_info()
     print("build info:", info or "(all units in their preferred form)")
     assert "error" not in info.lower()
+    units = sorted(set(re.findall(r"jet_wide_(\d)_(\d)_(\d)", info))) or [("2", "2", "0")]
+    pde_of = {(1, 1): "heat", (1, 2): "burgers", (1, 3): "kdv", (1, 4): "cahn_hilliard", (2, 2): "wave", (2, 0): "pendulum"}
+    act_of = {v: k for k, v in _lib.ACT.items()}
+    for nt, nx, act in units:
+        # width 128 is where the two MFMA forms differ most in register pressure; fourier covers encoder + MLP units
+        if act_of[int(act)] == "sin":  # the sine units are SIREN's
+            spec = O.ArchSpec("siren", hidden_dim=128, num_layers=3, omega_0=4.0)
+        else:
+            spec = O.ArchSpec("fourier", hidden_dim=128, num_layers=3, mapping_size=32, scale=3.0, activation=act_of[int(act)])
+        pde = O.PdeSpec(name=pde_of[(int(nt), int(nx))], parameters={"c": 1.3, "alpha": 0.05, "epsilon": 0.05})
+        sd = O.init_state_dict(spec, seed=int(nt) * 100 + int(nx) * 10 + int(act))
+        torch.manual_seed(7)
+        x, t = O.sample_uniform(pde, 400)
+        r_o, L_o, g_o = O.residual_loss_and_grad(pde, spec, {k: v.double() for k, v in sd.items()}, x.double(), t.double())
+        prog, names = program_from_spec(spec, sd, dev)
+        flat = E.new_flat_grad(prog, dev)
+        r, s = E.residual_loss_grad(prog, pde_desc_from_spec(pde), x.to(dev), t.to(dev), 1.0 / x.shape[0], flat, want_residual=True)
+        tol = TOL if act_of[int(act)] != "relu" else 1e-4  # relu kinks: a point within fp32 of 0 flips a branch
+        assert rel_l2(r.cpu(), r_o) <= tol, (nt, nx, act, rel_l2(r.cpu(), r_o))
+        by_name = {n: g for n, g in zip(names, E.split_flat_grad(prog, flat)) if g is not None}
+        keys = [k for k in g_o if k in by_name]
+        got = torch.cat([by_name[k].flatten().cpu() for k in keys])
+        want = torch.cat([g_o[k].flatten() for k in keys])
+        assert rel_l2(got, want) <= tol, (nt, nx, act, rel_l2(got, want))
 
 
 @pytest.mark.parametrize("tag", ["burgers_fourier_3x32", "burgers_feedforward_3x32", "kdv_siren_3x32"])
@@ -311,7 +341,8 @@ def test_piecewise_linear_activations(act, dev):
     assert rel_l2(got, want) <= 1e-4, f"{rel_l2(got, want):.3e}"
 
 
-@pytest.mark.parametrize("arch,dim,pde_name", [("feedforward", 2, "heat"), ("fourier", 2, "cahn_hilliard"), ("siren", 3, "heat")])
+@pytest.mark.parametrize("arch,dim,pde_name", [("feedforward", 2, "heat"), ("fourier", 2, "cahn_hilliard"), ("siren", 3, "heat"),
+                                               ("feedforward", 2, "black_scholes"), ("resnet", 2, "black_scholes")])
 def test_multi_dimensional_inputs(arch, dim, pde_name, dev):
     """input_dim 3 and 4 (x, y[, z], t) through the MLP kernels; as in the reference, every spatial term of a >= 2-D
     residual vanishes, which the oracle reproduces."""
@@ -320,7 +351,7 @@ def test_multi_dimensional_inputs(arch, dim, pde_name, dev):
     import oracle as O
 
     spec = O.ArchSpec(arch, input_dim=dim + 1, hidden_dim=64, num_layers=3, mapping_size=16, scale=2.0, omega_0=5.0)
-    pde = O.PdeSpec(name=pde_name, dimension=dim, domain=((0.0, 1.0),) * dim, parameters={"alpha": 0.05, "epsilon": 0.05})
+    pde = O.PdeSpec(name=pde_name, dimension=dim, domain=((0.0, 1.0),) * dim, parameters={"alpha": 0.05, "epsilon": 0.05, "r": 0.07, "sigma": 0.3})
     sd = O.init_state_dict(spec, seed=51)
     torch.manual_seed(52)
     x, t = torch.rand(137, dim), torch.rand(137, 1)
