@@ -352,27 +352,55 @@ class PDETrainer:
             "x_all": x_all, "t_all": t_all, "terms": terms, "n_bc": len(terms) - 1, "rw": float(rw),
             "term_losses": torch.zeros(len(terms), dtype=torch.float32, device=dev),
             "cot": torch.zeros(1, nb + ni, dtype=torch.float32, device=dev),
+            "grad_side": torch.zeros(n, dtype=torch.float32, device=dev),
             "summary": torch.zeros(4, dtype=torch.float32, device=dev),
             "betas": g["betas"], "eps": g["eps"], "wd": g["weight_decay"],
         }
         return self._flat
 
-    def _manual_launches(self, x, t):
+    def _manual_launches(self, x, t, side=None):
         """One optimiser step as a fixed launch sequence, no autograd (pinnrl/training/trainer.py:686-698 with
         pinnrl/pdes/pde_base.py:1086-1235 inlined): zero the flat gradient; residual + mean l(r) + d/dtheta in one
         launch; network values on the 200 boundary + 100 initial points; their loss terms and cotangents; their
-        reverse sweep into the same flat gradient; clip_grad_norm_ + Adam over the flat buffers."""
+        reverse sweep; clip_grad_norm_ + Adam over the flat buffers.
+
+        `side`: a second stream for the boundary / initial chain (forward, loss terms, reverse sweep into its own
+        gradient buffer).  The residual launch leaves most CUs idle during its last tile round (1 555 tiles on 256 CUs:
+        19 CUs run a seventh tile), which is where the side chain's 10 tiles then run; the two gradients are added
+        after the join, so no two launches ever write the same buffer concurrently."""
         F = self._flat
         prog = self.model.program()
         pd = self.pde._pde_desc()
         n, N = F["n"], x.shape[0]
+        loss_name, delta = self.pde._loss_function_name(), self.pde._huber_delta()
+
+        def boundary_chain(grad, summary):
+            u = _E.jets_forward(prog, F["x_all"], F["t_all"], 0, 0)
+            _E.point_losses(u[0], F["terms"], loss_name, delta, F["term_losses"], F["cot"][0],
+                            residual_sum=F["grad"][n : n + 1] if summary else None, residual_scale=1.0 / float(N),
+                            residual_weight=F["rw"], n_boundary_terms=F["n_bc"], summary4=F["summary"] if summary else None)
+            _E.jets_backward(prog, F["x_all"], F["t_all"], 0, 0, F["cot"], grad)
+            return u
+
         F["grad"].zero_()
-        _E.residual_loss_grad(prog, pd, x, t, F["rw"] / float(N), F["grad"][:n], loss_sum=F["grad"][n : n + 1])
-        u = _E.jets_forward(prog, F["x_all"], F["t_all"], 0, 0)
-        _E.point_losses(u[0], F["terms"], self.pde._loss_function_name(), self.pde._huber_delta(), F["term_losses"],
-                        F["cot"][0], residual_sum=F["grad"][n : n + 1], residual_scale=1.0 / float(N), residual_weight=F["rw"],
-                        n_boundary_terms=F["n_bc"], summary4=F["summary"])
-        _E.jets_backward(prog, F["x_all"], F["t_all"], 0, 0, F["cot"], F["grad"][:n])
+        if side is None:
+            _E.residual_loss_grad(prog, pd, x, t, F["rw"] / float(N), F["grad"][:n], loss_sum=F["grad"][n : n + 1])
+            boundary_chain(F["grad"][:n], True)
+        else:
+            main = torch.cuda.current_stream(self.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                F["grad_side"].zero_()
+                u = boundary_chain(F["grad_side"], False)
+            _E.residual_loss_grad(prog, pd, x, t, F["rw"] / float(N), F["grad"][:n], loss_sum=F["grad"][n : n + 1])
+            main.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                u.record_stream(main)
+            F["grad"][:n].add_(F["grad_side"])
+            # the {residual, boundary, initial, total} summary needs the residual launch's loss sum: the (3 us) loss-term
+            # kernel runs once more here; it rewrites the same cotangents
+            _E.point_losses(u[0], F["terms"], loss_name, delta, F["term_losses"], F["cot"][0], residual_sum=F["grad"][n : n + 1],
+                            residual_scale=1.0 / float(N), residual_weight=F["rw"], n_boundary_terms=F["n_bc"], summary4=F["summary"])
         _E.adam_clip_step(F["theta"], F["grad"], F["m"], F["v"], F["lr"], F["step"], F["scratch"], beta1=F["betas"][0],
                           beta2=F["betas"][1], eps=F["eps"], weight_decay=F["wd"],
                           max_norm=float(self.config.training.gradient_clipping))
@@ -385,8 +413,8 @@ class PDETrainer:
         """Capture ONE whole training step in a HIP graph and return `(replay, losses)`: `replay()` runs a step on a
         fresh device-side sample, `losses` is the dict of STATIC loss tensors it refreshes.
 
-        The captured step contains no autograd at all: it is `_manual_launches` — six kernels of this library plus the
-        sampler's handful of element-wise ones — writing into persistent flat buffers (parameters, gradient, Adam
+        The captured step contains no autograd at all: it is `_manual_launches` — a handful of kernels of this library (the boundary /
+        initial chain forked onto a second stream beside the residual launch) plus the sampler's element-wise ones — writing into persistent flat buffers (parameters, gradient, Adam
         moments; the parameters of the model become views of the flat buffer).  Nothing in it depends on autograd
         nodes of earlier eager steps, so it is safe to call after any number of `train_step`s (round 1's capture of
         `loss.backward()` crashed on a stale AccumulateGrad node).  The learning rate lives in a device scalar that
@@ -397,14 +425,16 @@ class PDETrainer:
             raise NotImplementedError(f"graph capture covers the plain Adam step only ({why})")
         self._build_flat_state()
 
+        overlap = torch.cuda.Stream(device=self.device)  # boundary / initial chain, forked and joined inside the step
+
         def step():
             x, t = self._sample(batch_size)
-            self._manual_launches(x, t)
+            self._manual_launches(x, t, side=overlap)
 
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):  # sizes the engine's scratch and the allocator pools before capture
+            for _ in range(max(warmup, 1)):  # sizes the engine's scratch (both streams) and the allocator pools before capture
                 step()
         torch.cuda.current_stream(self.device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()

@@ -37,7 +37,7 @@ def main():
         return trainer.train_step(x, t)
 
     n = int(pde.generate_collocation_points(args.points)[0].shape[0])
-    if args.graph:  # capture first: no autograd graph of an earlier eager step may still be alive at capture time
+    if args.graph:  # the captured step contains no autograd (safe after eager steps too)
         run, losses = trainer.make_graphed_step(args.points)
     else:
         run = step
