@@ -524,6 +524,14 @@ int gemm_prefetch_mode() {  // PINN_LM_PREFETCH=0|1 (experiments), read once
   return v;
 }
 
+bool gemm_wres_off() {  // PINN_LM_WRES=0 (experiments: the streaming kernel everywhere), read once
+  static const bool v = [] {
+    const char* e = getenv("PINN_LM_WRES");
+    return e && atoi(e) == 0;
+  }();
+  return v;
+}
+
 template <bool COLS>
 hipError_t launch_gemm(const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
@@ -533,6 +541,26 @@ hipError_t launch_gemm(const GemmArgs& g0, hipStream_t st) {
   const int items = (g.ncb + kCB - 1) / kCB;
   const size_t lds = lm_gemm_lds_bytes(depth);
   hipError_t e;
+  if constexpr (!COLS) {
+    // weight-resident kernel where the wave's slice fits the register file and the double-buffered stage the LDS
+    const int nch = depth >> 5;
+    const int rt = out_rows > 128 ? 8 : 4;
+#define PINN_WRES(NCH_, RT_)                                                                         \
+  if (nch == NCH_ && rt == RT_ && !gemm_wres_off()) {                                               \
+    auto kern = lm_gemm_wres<NCH_, RT_>;                                                             \
+    const size_t wl = lm_gemm_wres_lds_bytes(NCH_, RT_);                                             \
+    if ((e = allow_lds(reinterpret_cast<const void*>(kern), wl)) != hipSuccess) return e;            \
+    const int gy = (out_rows + 32 * RT_ - 1) / (32 * RT_);                                           \
+    const int wi = (g.ncb + 2 * (8 / RT_) - 1) / (2 * (8 / RT_));                                    \
+    int gx = num_cus() / gy;                                                                         \
+    if (gx < 1) gx = 1;                                                                              \
+    if (gx > wi) gx = wi;                                                                            \
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(kWresThreads), wl, st, g);                           \
+    return hipGetLastError();                                                                        \
+  }
+    PINN_WRES(8, 8) PINN_WRES(4, 8) PINN_WRES(4, 4)
+#undef PINN_WRES
+  }
   if (out_rows > 128) {
     auto kern = lm_gemm<COLS, 2>;
     if ((e = allow_lds(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return e;

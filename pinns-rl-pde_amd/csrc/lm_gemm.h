@@ -57,6 +57,39 @@ __device__ __forceinline__ void ld_cols(WFrag16& w, const float* W, int ld, unsi
     }
 }
 
+// Bias and add records around an accumulator tile.  The first version's epilogue did load-add-store per element; a
+// load issued after a store makes s_waitcnt vmcnt wait for that store's round trip (the counter is in order), 16
+// times per tile: 165 of 579 us per launch (rocprofv3 ablation, C3).  Now the bias is the tile's start value, and the
+// add records (skip-path cotangents: large next to the products, so they are still added LAST, to the finished sum)
+// are loaded for all tiles of a wave before its first store.
+__device__ __forceinline__ void acc_start(f32x16& acc, const float* bias_rows, int lh) {
+  if (bias_rows) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias_rows[acc_row(r, lh)];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void acc_add_records(f32x16 (&acc)[NT], const float* add, const long long (&base)[NT], const bool (&live)[NT],
+                                                int lh) {
+  float t[NT][16];
+#pragma unroll
+  for (int c = 0; c < NT; ++c)
+    if (live[c]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[c][r] = add[base[c] + acc_row(r, lh) * kT];
+    }
+#pragma unroll
+  for (int c = 0; c < NT; ++c)
+    if (live[c]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] += t[c][r];
+    }
+}
+
 // acc[c] += Wslice(32 x 32 nc) . img[c][0 .. 32 nc)[n]      img: [kCB][kc_rows][kTP]
 template <bool COLS>
 __device__ __forceinline__ void gemm_core(f32x16 (&acc)[kCB], const float* W, int ld, unsigned lane_off, int nc,
@@ -155,15 +188,23 @@ __global__ __launch_bounds__(kThreads, 2) void lm_gemm(const GemmArgs a) {
   };
 
   f32x16 acc[NTILE][kCB];
+  auto start_tiles = [&](int q) {  // accumulators of the item that begins at stage q
+    const int cb0 = stage_item(q) * kCB;
 #pragma unroll
-  for (int jt = 0; jt < NTILE; ++jt)
+    for (int jt = 0; jt < NTILE; ++jt) {
+      const int row0 = row_blk + (L.wave + kWaves * jt) * 32;
 #pragma unroll
-    for (int c = 0; c < kCB; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[jt][c][r] = 0.0f;
+      for (int c = 0; c < kCB; ++c) {
+        const int cb = cb0 + c;
+        const bool with_bias = row0 < out_rows && cb < a.ncb && !COLS && a.bias && (cb % a.K) == 0;
+        acc_start(acc[jt][c], with_bias ? a.bias + row0 : nullptr, L.lh);
+      }
+    }
+  };
   if (nstages > 0) {
     fetch(0);
     stash(0);
+    start_tiles(0);
   }
   __syncthreads();
   for (int q = 0; q < nstages; ++q) {
@@ -189,41 +230,178 @@ __global__ __launch_bounds__(kThreads, 2) void lm_gemm(const GemmArgs a) {
     }
     if (!a.prefetch && q + 1 < nstages) fetch(q + 1);
     if ((q % nk) == nk - 1) {
-      // epilogue: bias on value-stream blocks, optional adds, 128-byte row segments per half wave
+      // epilogue: add records (all loads first), then stores only; 128-byte row segments per half wave
       const int cb0 = stage_item(q) * kCB;
 #pragma unroll
       for (int jt = 0; jt < NTILE; ++jt) {
         const int row0 = row_blk + (L.wave + kWaves * jt) * 32;
         if (row0 < out_rows) {
+          long long base[kCB];
+          bool live[kCB];
 #pragma unroll
           for (int c = 0; c < kCB; ++c) {
-            const int cb = cb0 + c;
-            if (cb < a.ncb) {
-              const bool with_bias = !COLS && a.bias && (cb % a.K) == 0;
-              const long long base = ((long long)cb * y_rows + row0) * kT + L.ln;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int rr = acc_row(r, L.lh);
-                float v = acc[jt][c][r];
-                if (with_bias) v += a.bias[row0 + rr];
-                if (a.add0) v += a.add0[base + rr * kT];
-                if (a.add1) v += a.add1[base + rr * kT];
-                a.Y[base + rr * kT] = v;
-              }
-            }
+            live[c] = cb0 + c < a.ncb;
+            base[c] = ((long long)(cb0 + c) * y_rows + row0) * kT + L.ln;
           }
+          if (a.add0) acc_add_records<kCB>(acc[jt], a.add0, base, live, L.lh);
+          if (a.add1) acc_add_records<kCB>(acc[jt], a.add1, base, live, L.lh);
+#pragma unroll
+          for (int c = 0; c < kCB; ++c)
+            if (live[c]) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) a.Y[base[c] + acc_row(r, L.lh) * kT] = acc[jt][c][r];
+            }
         }
-#pragma unroll
-        for (int c = 0; c < kCB; ++c)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[jt][c][r] = 0.0f;
       }
+      if (q + 1 < nstages) start_tiles(q + 1);
     }
     __syncthreads();  // every wave has finished reading this stage's image
     if (q + 1 < nstages) stash(q + 1);
     __syncthreads();
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-resident rows-form GEMM.  Y[cb] = W X[cb] with reduction depth 32 NCH <= 256.
+//
+// The weights of a layer are tiny next to its batch, yet lm_gemm re-streams a wave's 32 x depth slice from L2 for
+// every staged image (and exposes the first chunk's latency each time): its matrix pipe sits at 58-66 % (rocprofv3,
+// profiles/r02_C3.md).  Here a 512-thread workgroup (8 waves, one per CU) keeps each wave's slice IN REGISTERS for the
+// whole launch (16 NCH VGPRs, 128 at depth 256), double-buffers the staged column blocks in LDS (one barrier per
+// stage; the next image's rows are in flight during the MFMAs), and the inner loop is nothing but ds_read_b32 with
+// immediate offsets + MFMA.  Waves: RT row tiles x CG = 8 / RT column groups, each wave 2 column blocks per stage.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWresThreads = 512;
+
+template <int NCH, int RT>
+__global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a) {
+  constexpr int CG = 8 / RT;
+  constexpr int SB = 2 * CG;                      // column blocks per stage
+  constexpr int DEPTH = 32 * NCH;
+  constexpr int kBlk = DEPTH * kTP;               // floats per staged block
+  constexpr int kQuads = SB * DEPTH * 8;          // 16-byte words per stage
+  constexpr int kPre = kQuads / kWresThreads;     // per thread (8 at depth 256 / SB 2)
+  static_assert(kQuads % kWresThreads == 0, "stage must divide over the workgroup");
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][SB][DEPTH][kTP]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = tid & 31, lh = (tid >> 5) & 1;
+  const int rt = wave % RT, cg = wave / RT;
+  const int row0 = (int)blockIdx.y * (32 * RT) + 32 * rt;
+  const bool row_ok = row0 < a.w_rows;
+  const int y_rows = a.w_rows;
+  const int items = (a.ncb + SB - 1) / SB;
+  const int my_items = items > (int)blockIdx.x ? (items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+
+  WFrag16 w[NCH];
+  {
+    const unsigned lane_off = static_cast<unsigned>(tid & 63) * 16u;
+    const float* wt = a.W + (long long)((row_ok ? row0 : 0) >> 5) * NCH * 1024;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) ld_rows(w[ch], wt, lane_off, ch);
+  }
+
+  f32x4 pre[kPre];
+  auto fetch = [&](int q) {
+    const int cb0 = ((int)blockIdx.x + q * (int)gridDim.x) * SB;
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+      const int q4 = u * kWresThreads + tid;       // word index inside the stage: [block][k][8 quads]
+      const int c = q4 / (DEPTH * 8), r = q4 % (DEPTH * 8);
+      const int cb = cb0 + c < a.ncb ? cb0 + c : a.ncb - 1;  // clamped, unconditional (never stored past the end)
+      pre[u] = *reinterpret_cast<const f32x4*>(a.X + (long long)cb * kT * DEPTH + 4 * r);
+    }
+  };
+  auto stash = [&](int buf) {
+    float* dst = smem + buf * (SB * kBlk);
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+      const int q4 = u * kWresThreads + tid;
+      const int c = q4 / (DEPTH * 8), r = q4 % (DEPTH * 8);
+      *reinterpret_cast<f32x4*>(dst + c * kBlk + (r >> 3) * kTP + 4 * (r & 7)) = pre[u];
+    }
+  };
+
+  if (my_items > 0) {
+    fetch(0);
+    stash(0);
+  }
+  float* sbias = smem + 2 * SB * kBlk;  // this block's 32 RT bias values
+  if (tid < 32 * RT) {
+    const int row = (int)blockIdx.y * (32 * RT) + tid;
+    sbias[tid] = a.bias && row < a.w_rows ? a.bias[row] : 0.0f;
+  }
+  __syncthreads();
+  for (int q = 0; q < my_items; ++q) {
+    f32x16 acc[2];
+    {
+      const int cb0 = ((int)blockIdx.x + q * (int)gridDim.x) * SB + 2 * cg;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int cb = cb0 + c;
+        acc_start(acc[c], row_ok && cb < a.ncb && a.bias && (cb % a.K) == 0 ? sbias + 32 * rt : nullptr, lh);
+      }
+    }
+    if (q + 1 < my_items) fetch(q + 1);
+    const float* col = smem + (q & 1) * (SB * kBlk) + (2 * cg) * kBlk + (4 * lh) * kTP + ln;
+    float bc[4][2], bn[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bc[i][c] = col[c * kBlk + i * kTP];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        constexpr int last = 32 * NCH - 8;
+        const int kn = (32 * ch + 8 * g) < last ? 32 * ch + 8 * (g + 1) : last;  // the final group re-reads itself
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) bn[i][c] = col[c * kBlk + (kn + i) * kTP];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ch].g[g][i], bc[i][c], acc[c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) bc[i][c] = bn[i][c];
+      }
+    }
+    if (row_ok) {  // epilogue: add records (all loads first), then stores only; 128-byte row segments per half wave
+      const int cb0 = ((int)blockIdx.x + q * (int)gridDim.x) * SB + 2 * cg;
+      long long base[2];
+      bool live[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        live[c] = cb0 + c < a.ncb;
+        base[c] = ((long long)(cb0 + c) * y_rows + row0) * kT + ln;
+      }
+      // one tile at a time: 16 temporaries (32 would spill beside the resident weights and the in-flight stage)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        f32x16(&one)[1] = reinterpret_cast<f32x16(&)[1]>(acc[c]);
+        const long long b1[1] = {base[c]};
+        const bool l1[1] = {live[c]};
+        if (a.add0) acc_add_records<1>(one, a.add0, b1, l1, lh);
+        if (a.add1) acc_add_records<1>(one, a.add1, b1, l1, lh);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        if (live[c]) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a.Y[base[c] + acc_row(r, lh) * kT] = acc[c][r];
+        }
+    }
+    if (q + 1 < my_items) stash((q + 1) & 1);
+    __syncthreads();
+  }
+}
+
+inline size_t lm_gemm_wres_lds_bytes(int nch, int rt) { return sizeof(float) * (2u * (2u * (8 / rt)) * (32u * nch) * kTP + 32u * rt); }
 
 inline size_t lm_gemm_lds_bytes(int depth) { return sizeof(float) * (size_t)kCB * (depth < kKC ? depth : kKC) * kTP; }
 
