@@ -301,24 +301,25 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
     for (int ch = 0; ch < NCH; ++ch) ld_rows(w[ch], wt, lane_off, ch);
   }
 
+  static_assert((DEPTH * 8) % kWresThreads == 0, "a stage word row must not straddle two column blocks");
   f32x4 pre[kPre];
-  auto fetch = [&](int q) {
+  const unsigned toff = static_cast<unsigned>(tid) * 16u;
+  auto fetch = [&](int q) {  // word u * 512 + tid of the stage: block and first word are compile-time, the base is uniform
     const int cb0 = ((int)blockIdx.x + q * (int)gridDim.x) * SB;
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
-      const int q4 = u * kWresThreads + tid;       // word index inside the stage: [block][k][8 quads]
-      const int c = q4 / (DEPTH * 8), r = q4 % (DEPTH * 8);
+      const int c = (u * kWresThreads) / (DEPTH * 8), r0 = (u * kWresThreads) % (DEPTH * 8);
       const int cb = cb0 + c < a.ncb ? cb0 + c : a.ncb - 1;  // clamped, unconditional (never stored past the end)
-      pre[u] = *reinterpret_cast<const f32x4*>(a.X + (long long)cb * kT * DEPTH + 4 * r);
+      const float* base = uniform_ptr(a.X + (long long)cb * kT * DEPTH + 4 * r0);
+      pre[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + toff);
     }
   };
   auto stash = [&](int buf) {
-    float* dst = smem + buf * (SB * kBlk);
+    float* dst = smem + buf * (SB * kBlk) + (tid >> 3) * kTP + 4 * (tid & 7);
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
-      const int q4 = u * kWresThreads + tid;
-      const int c = q4 / (DEPTH * 8), r = q4 % (DEPTH * 8);
-      *reinterpret_cast<f32x4*>(dst + c * kBlk + (r >> 3) * kTP + 4 * (r & 7)) = pre[u];
+      const int c = (u * kWresThreads) / (DEPTH * 8), r0 = (u * kWresThreads) % (DEPTH * 8);
+      *reinterpret_cast<f32x4*>(dst + c * kBlk + (r0 >> 3) * kTP) = pre[u];
     }
   };
 
@@ -332,6 +333,17 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
     sbias[tid] = a.bias && row < a.w_rows ? a.bias[row] : 0.0f;
   }
   __syncthreads();
+  f32x16 prev[2];
+  float* prev_base[2] = {a.Y, a.Y};  // wave-uniform block bases; the lane part of every address is `voff`
+  bool prev_live[2] = {false, false};
+  const unsigned voff = static_cast<unsigned>(4 * lh * kT + ln) * 4u;
+  auto row_ptr = [&](float* base, int r) {  // accumulator register r -> its row of the block (immediate offset)
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(base + ((r & 3) + 8 * (r >> 2)) * kT) + voff);
+  };
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) prev[c][r] = 0.0f;
   for (int q = 0; q < my_items; ++q) {
     f32x16 acc[2];
     {
@@ -342,7 +354,6 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
         acc_start(acc[c], row_ok && cb < a.ncb && a.bias && (cb % a.K) == 0 ? sbias + 32 * rt : nullptr, lh);
       }
     }
-    if (q + 1 < my_items) fetch(q + 1);
     const float* col = smem + (q & 1) * (SB * kBlk) + (2 * cg) * kBlk + (4 * lh) * kTP + ln;
     float bc[4][2], bn[4][2];
 #pragma unroll
@@ -355,6 +366,19 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
       for (int g = 0; g < 4; ++g) {
         constexpr int last = 32 * NCH - 8;
         const int kn = (32 * ch + 8 * g) < last ? 32 * ch + 8 * (g + 1) : last;  // the final group re-reads itself
+        // the PREVIOUS stage's tiles leave during the first half of this stage's MFMAs (kSt stores per k-group),
+        // the NEXT stage's rows are requested at half time: `prev` and `pre` never live together
+        constexpr int kGroupsHalf = 2 * NCH;
+        constexpr int kSt = 32 / kGroupsHalf;
+        const int gi = 4 * ch + g;
+        if (gi < kGroupsHalf) {
+#pragma unroll
+          for (int e = 0; e < kSt; ++e) {
+            const int idx = gi * kSt + e, c = idx >> 4, r = idx & 15;
+            if (prev_live[c]) *row_ptr(prev_base[c], r) = prev[c][r];
+          }
+        }
+        if (gi == kGroupsHalf && q + 1 < my_items) fetch(q + 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -371,34 +395,44 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
           for (int c = 0; c < 2; ++c) bc[i][c] = bn[i][c];
       }
     }
-    if (row_ok) {  // epilogue: add records (all loads first), then stores only; 128-byte row segments per half wave
+    {  // hand the finished tiles over: add records now (all loads before any store), stores during the next stage
       const int cb0 = ((int)blockIdx.x + q * (int)gridDim.x) * SB + 2 * cg;
-      long long base[2];
-      bool live[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        live[c] = cb0 + c < a.ncb;
-        base[c] = ((long long)(cb0 + c) * y_rows + row0) * kT + ln;
-      }
-      // one tile at a time: 16 temporaries (32 would spill beside the resident weights and the in-flight stage)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        f32x16(&one)[1] = reinterpret_cast<f32x16(&)[1]>(acc[c]);
-        const long long b1[1] = {base[c]};
-        const bool l1[1] = {live[c]};
-        if (a.add0) acc_add_records<1>(one, a.add0, b1, l1, lh);
-        if (a.add1) acc_add_records<1>(one, a.add1, b1, l1, lh);
+        prev_live[c] = row_ok && cb0 + c < a.ncb;
+        prev_base[c] = uniform_ptr(a.Y + ((long long)(cb0 + c) * y_rows + row0) * kT);
       }
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-        if (live[c]) {
+      for (int c = 0; c < 2; ++c) {  // one tile at a time: 16 temporaries
+        if (!prev_live[c]) continue;
+        const long long blk = prev_base[c] - a.Y;
+        if (a.add0) {
+          float t[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) a.Y[base[c] + acc_row(r, lh) * kT] = acc[c][r];
+          for (int r = 0; r < 16; ++r) t[r] = *row_ptr(const_cast<float*>(a.add0) + blk, r);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[c][r] += t[r];
         }
+        if (a.add1) {
+          float t[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = *row_ptr(const_cast<float*>(a.add1) + blk, r);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[c][r] += t[r];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) prev[c] = acc[c];
     }
     if (q + 1 < my_items) stash((q + 1) & 1);
     __syncthreads();
   }
+#pragma unroll
+  for (int c = 0; c < 2; ++c)  // the last stage's tiles
+    if (prev_live[c]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) *row_ptr(prev_base[c], r) = prev[c][r];
+    }
 }
 
 inline size_t lm_gemm_wres_lds_bytes(int nch, int rt) { return sizeof(float) * (2u * (2u * (8 / rt)) * (32u * nch) * kTP + 32u * rt); }
