@@ -13,9 +13,9 @@
 //     dW  += Zbar V^T, db += Zbar 1    lm_gemm.h  (accumulated over all tiles of a launch in registers)
 //     Zbar_prev = prologue^T(Vbar)     lm_ew.h    (+ LayerNorm / encoder parameter gradients)
 //
-// and a batch is processed in chunks so that the short-lived records stay in the 256 MB Infinity Cache.  The host
-// side (lm_engine.hip) turns a PinnNetDesc into that launch list; tests/jet_model.py::net_program is its executable
-// specification.
+// and a batch is processed in chunks of ~1 GB per record (bounded workspace; measured: bigger chunks are faster, the
+// records are streamed from HBM, not held in the Infinity Cache).  The host side (lm_engine.hip) turns a PinnNetDesc
+// into that launch list; tests/jet_model.py::net_program is its executable specification.
 //
 // Record layout: R[tile][stream s][feature f][32 points], f < Hp = features rounded up to 32 (padding rows are
 // written as zeros).  One (tile, stream) pair is a *column block*: a contiguous Hp x 32 fp32 slab, which is at the

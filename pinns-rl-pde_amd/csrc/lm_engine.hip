@@ -89,15 +89,17 @@ int num_cus() {
 }
 
 // Bytes of one record per chunk the sizing aims at; PINN_LM_RECORD_MB overrides it, read once.  Measured on MI355X
-// (tools/bench_configs.py, C3 / C4 / C5): bigger is faster all the way — 96 MB 41.5 / 46.0 / 177 ms, 512 MB 33.8 /
-// 36.8 / 143 ms: what counts is full waves of work per launch and few one-off weight-gradient flushes, not Infinity
-// Cache residency of the records.  512 MB keeps a 10^6-point batch of the widest supported network within ~30 GB.
+// (tools/bench_configs.py, C3 / C4 / C5): bigger is faster until every launch has >= ~25 units of work per workgroup —
+// 96 MB 41.5 / 46.0 / 177 ms, 512 MB 33.8 / 36.8 / 143 ms, then flat for C3 / C4 and 138 -> 134 -> 132 -> 131 ms for C5
+// at 512 / 1024 / 2048 / 4096 MB: what counts is full waves of work per launch and few one-off weight-gradient
+// flushes, not Infinity Cache residency of the records.  1 GB keeps a 10^6-point batch of the widest supported
+// network within ~60 GB of the 288.
 size_t record_target_bytes() {
   static size_t v = 0;
   if (!v) {
     const char* e = getenv("PINN_LM_RECORD_MB");
     const long mb = e ? atol(e) : 0;
-    v = (size_t)(mb > 0 ? mb : 512) << 20;
+    v = (size_t)(mb > 0 ? mb : 1024) << 20;
   }
   return v;
 }
