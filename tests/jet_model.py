@@ -694,6 +694,10 @@ def net_program(spec, sd: Mapping[str, Tensor]) -> Dict:
         src, lnq, act = {"kind": "coords_linear", "enc": lin("model.input_proj")}, None, (spec.activation, 0.0)
         for l in range(spec.num_layers):
             pa, pf = f"model.layers.{l}.0.", f"model.layers.{l}.1."
+            # value and projection as two nodes, as the reference computes them.  The engine runs them as ONE GEMM with
+            # W_p W_v / W_p b_v + b_p formed per call (lm_engine.hip::lm_merge_pv_kernel) and maps the merged gradient
+            # back: dW_p = G W_v^T + g b_v^T, dW_v = W_p^T G, db_v = W_p^T g, db_p = g — the same function, so both forms
+            # are held to the oracle (GPU parity tests for the engine, test_jet_model.py for this one).
             nodes.append({"src": src, "ln": lnq, "skip": None, "act": act, "lin": lin(pa + "value"), "add": None})
             nv = len(nodes) - 1
             nodes.append({"src": {"kind": "rec", "node": nv}, "ln": None, "skip": None, "act": None, "lin": lin(pa + "proj"),
