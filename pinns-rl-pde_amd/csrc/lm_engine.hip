@@ -953,7 +953,7 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
         g.v_rows = round32(nd.Hin);
         g.ncb = ncb;
         g.K = K;
-        const bool big = g.z_rows >= 256 && g.v_rows >= 256;  // 256 x 256 blocks on eight waves
+        const bool big = g.z_rows >= 256 && g.v_rows >= 128;  // 256-row blocks on eight waves (x up to 256 columns)
         const int gy = big ? (g.z_rows + kNt8 - 1) / kNt8 : (g.z_rows + 127) / 128;
         const int gz = big ? (g.v_rows + kNt8 - 1) / kNt8 : (g.v_rows + kNtCols - 1) / kNtCols;
         // splits: fill the chip, but leave every workgroup >= 12 column blocks to amortise its one-off flush
