@@ -105,8 +105,16 @@ class BaseNetwork(nn.Module):
             trainable = [isinstance(t, nn.Parameter) for t in tensors]
             prog = _E.NetProgram(tensors=tensors, trainable=trainable, **spec)
             prog.names = list(sd.keys())
+            prog.set_deterministic(getattr(self, "_deterministic", False))
             self._prog_cache = (key, prog)
         return self._prog_cache[1]
+
+    def set_deterministic(self, on: bool = True) -> None:
+        """Bit-reproducible weight gradients (PINN_FLAG_DETERMINISTIC: fixed-order reductions in the layer-major
+        engine); kept across rebuilds of the program.  Reference anchor: tests/unit_tests/test_benchmarks.py:61-64."""
+        self._deterministic = bool(on)
+        if self._prog_cache is not None:
+            self._prog_cache[1].set_deterministic(self._deterministic)
 
     def jets(self, x: torch.Tensor, t: torch.Tensor, time_order: int = 0, space_order: int = 0) -> torch.Tensor:
         """(K, N) = [u, d/dt.., d/dx..] in one launch; differentiable w.r.t. the parameters."""
@@ -371,6 +379,9 @@ class PINNModel(BaseNetwork):
 
     def _program_spec(self):
         return self.model._program_spec()
+
+    def set_deterministic(self, on: bool = True) -> None:
+        self.model.set_deterministic(on)
 
     def program(self):
         prog = self.model.program()

@@ -316,7 +316,7 @@ def test_deterministic_flag_gives_bit_identical_gradients(dev):
     from hip_helpers import pde_desc_from_spec, program_from_spec
     from pinnrl_amd import engine as E
 
-    for tag in ("burgers_fourier_4x128", "allen_cahn_resnet_3x128", "kdv_siren_3x32"):
+    for tag in ("burgers_fourier_4x128", "allen_cahn_resnet_3x128", "kdv_siren_3x32", "burgers_attention_2x32"):
         spec, pde, sd, a, m = load_case(tag)
         prog, names = program_from_spec(spec, sd, dev)
         pd = pde_desc_from_spec(pde)
@@ -336,6 +336,28 @@ def test_deterministic_flag_gives_bit_identical_gradients(dev):
         for flat, s_ in runs[1:]:
             assert torch.equal(flat, runs[0][0]) and torch.equal(s_, runs[0][1]), tag
         assert rel_l2(runs[0][0].cpu(), ref.cpu()) <= 1e-5 and abs(float(runs[0][1]) - float(s_ref)) <= 1e-5 * abs(float(s_ref))
+
+
+def test_model_level_determinism_switch(dev):
+    """PINNModel.set_deterministic(True): two loss.backward() passes on the same batch give bit-identical .grad,
+    and the switch survives a rebuild of the program (parameters moved)."""
+    from __graft_entry__ import _burgers
+
+    cfg, model, pde = _burgers(dev, hidden=64, layers=3, mapping=16)
+    model.set_deterministic(True)
+    torch.manual_seed(5)
+    x, t = pde.generate_collocation_points(20000, strategy="uniform")
+    grads = []
+    for rep in range(2):
+        model.zero_grad()
+        pde.compute_loss(model, x, t)["residual"].backward()
+        grads.append(torch.cat([p.grad.flatten() for p in model.parameters()]).clone())
+        if rep == 0:
+            model.float()  # no-op cast; then force new storage so that program() rebuilds
+            for p in model.parameters():
+                p.data = p.data.clone()
+    assert torch.equal(grads[0], grads[1])
+    assert model.program().desc.flags & 2
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
