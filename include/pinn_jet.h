@@ -46,8 +46,10 @@ extern "C" {
 
 /* PinnNetDesc.flags */
 #define PINN_FLAG_LAYER_NORM 1    /* feedforward: a LayerNorm follows every hidden Linear (feedforward.py:43-45) */
-#define PINN_FLAG_DETERMINISTIC 2 /* weight gradients reduced in a fixed order: two launches on the same inputs give
-                                     bit-identical gradients (reference anchor: tests/unit_tests/test_benchmarks.py:61-64) */
+#define PINN_FLAG_DETERMINISTIC 2 /* weight gradients and loss reduced in a fixed order: two launches on the same inputs
+                                     give bit-identical results (reference anchor: tests/unit_tests/test_benchmarks.py:61-64).
+                                     Both engines: per-workgroup slab rows + ordered row sum; the workspace grows by
+                                     grid x parameter count floats */
 #define PINN_FLAG_LAYER_MAJOR 4   /* engine hint: run the layer-major engine even where the fused tile-major kernel
                                      applies (same results to rounding; tests run both) */
 

@@ -86,7 +86,17 @@ struct KernelArgs {
   float* tape;                              // BWD workspace
   long long tape_stride;                    // floats per workgroup
   unsigned long long* stamps;               // diagnostic builds (-DPINN_STAMPS) only: [grid][4 waves][kNumStamps] cycles
+  long long det_stride;                     // deterministic mode: the gradient / loss pointers above point into row 0 of a
+                                            // [grid][det_stride] slab and workgroup b adds (plainly) into row b; 0 = atomics
 };
+
+// Gradient / loss accumulation at the end of a workgroup (or per tile for layers beyond the persistent ones): float
+// atomics on the caller's tensors, or - deterministic mode - on this workgroup's own row of a [grid][det_stride] slab
+// (the pointers then point into row 0): nobody else touches that row, every address gets its adds in program order
+// (at most two per flush, which commute exactly from a zero start), and a fixed-order reduction sums the rows
+// afterwards (pinn_abi.hip).  One code path: the row offset is simply 0 when the mode is off.
+__device__ __forceinline__ long long det_row_offset(const KernelArgs& a) { return (long long)blockIdx.x * a.det_stride; }
+__device__ __forceinline__ void grad_add(float* p, float v, long long off) { atomicAdd(p + off, v); }
 
 // Every kernel of this family may use the whole 160 KB LDS of a CU as dynamic shared memory.  The attribute is set
 // ONCE per (kernel, device) — not per launch: it is a driver call on the launch path, and it is not allowed while

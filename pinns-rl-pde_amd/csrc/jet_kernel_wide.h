@@ -407,14 +407,14 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 template <int OFF, int NMAX, int NPT>
-__device__ __forceinline__ void flush_rows(const f32x16 (&pt)[NPT], const LayerDev& Ly, const Lane& L) {
+__device__ __forceinline__ void flush_rows(const f32x16 (&pt)[NPT], const LayerDev& Ly, const Lane& L, long long doff) {
   if (!Ly.dW || L.wave * 32 >= Ly.out_dim) return;
   float* base = Ly.dW + (long long)(L.wave * 32 + 4 * L.lh) * Ly.ld + L.ln;
 #pragma unroll
   for (int kt = 0; kt < NMAX; ++kt) {
     if (kt * 32 + L.ln < Ly.in_dim) {  // in_dim may end inside a k-tile (e.g. 24 Fourier features)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(base + (long long)((r & 3) + 8 * (r >> 2)) * Ly.ld + kt * 32, pt[OFF + kt][r]);
+      for (int r = 0; r < 16; ++r) grad_add(base + (long long)((r & 3) + 8 * (r >> 2)) * Ly.ld + kt * 32, pt[OFF + kt][r], doff);
     }
   }
 }
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
         if (Ly.db && tid < Ly.out_dim) {
           const float g = row_sum(X + tid * kTP);
           if (l < kPersist) pl[l * hmax + tid] += g;
-          else atomicAdd(Ly.db + tid, g);
+          else grad_add(Ly.db + tid, g, det_row_offset(a));
         }
         // abar_{l-1} = W^T zbar for all streams
         f32x4 rq0[K];
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dacc[kt][r] = 0.0f;
               gemm_outer_wide<K, 0, NKT, NKT>(dacc, ft, Ly.in_dim, X, A2, hmax, L);
-              flush_rows<0, NKT, NKT>(dacc, Ly, L);
+              flush_rows<0, NKT, NKT>(dacc, Ly, L, det_row_offset(a));
             }
           }
           if (l > 0 && kon) ew_backward_stream<ACT, NT, NX>(ab, pw, tape, l - 1, rq0, tid);
@@ -797,37 +797,38 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
   }
 
   // ---- one flush per workgroup ----
+  const long long doff = det_row_offset(a);  // deterministic mode: this workgroup's own slab row
   if (a.mode == MODE_PDE && a.loss_sum && L.wave == 0) {
     float sacc = L.lh == 0 ? ploss : 0.0f;
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-    if (tid == 0) atomicAdd(a.loss_sum, sacc);
+    if (tid == 0) grad_add(a.loss_sum, sacc, doff);
   }
   if constexpr (BWD) {
     if (net.db_out && L.wave == 0) {
       float g = L.lh == 0 ? pdb_out : 0.0f;
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) g += __shfl_xor(g, o);
-      if (tid == 0) atomicAdd(net.db_out, g);
+      if (tid == 0) grad_add(net.db_out, g, doff);
     }
     if (net.enc == ENC_LINEAR && net.d_encW && tid < net.enc_out) {
 #pragma unroll
       for (int cc = 0; cc < kMaxDin; ++cc)
-        if (cc < din) atomicAdd(net.d_encW + tid * din + cc, pl[(kPersist + cc) * hmax + tid]);
-      if (net.d_encb) atomicAdd(net.d_encb + tid, pl[(kPersist + kMaxDin) * hmax + tid]);
+        if (cc < din) grad_add(net.d_encW + tid * din + cc, pl[(kPersist + cc) * hmax + tid], doff);
+      if (net.d_encb) grad_add(net.d_encb + tid, pl[(kPersist + kMaxDin) * hmax + tid], doff);
     }
     if (net.dw_out) {  // dwo[wave][row][r]: rows 0,1 of a wave are the two point halves of lh = 0; 2,3 of lh = 1
       const int f = ft * 32 + acc_row(tid & 15, L.lh);
-      if (f < net.h_last) atomicAdd(net.dw_out + f, dwo[tid]);
+      if (f < net.h_last) grad_add(net.dw_out + f, dwo[tid], doff);  // two lanes (point halves) per feature: a + b == b + a
     }
 #pragma unroll
     for (int p = 0; p < kPersist; ++p) {
       if (p < nl) {
         const LayerDev Lp = uniform_layer(net.layer[p]);
-        if (Lp.db && tid < Lp.out_dim) atomicAdd(Lp.db + tid, pl[p * hmax + tid]);
-        if (p == 0) flush_rows<0, NA0, NPT>(pt, Lp, L);
-        else if (p == 1) flush_rows<NA0, NKT, NPT>(pt, Lp, L);
-        else flush_rows<NA0 + NKT, NKT, NPT>(pt, Lp, L);
+        if (Lp.db && tid < Lp.out_dim) grad_add(Lp.db + tid, pl[p * hmax + tid], doff);
+        if (p == 0) flush_rows<0, NA0, NPT>(pt, Lp, L, doff);
+        else if (p == 1) flush_rows<NA0, NKT, NPT>(pt, Lp, L, doff);
+        else flush_rows<NA0 + NKT, NKT, NPT>(pt, Lp, L, doff);
       }
     }
     PINN_STAMP(ST_BWD_FLUSH);

@@ -82,7 +82,7 @@ static float act_param_of(int act, float user) {
 // `num_tensors` entries, already validated against the descriptor.
 static bool build_wide(const PinnNetDesc* d, const float* const* w, float* const* g, NetDev* out) {
   if (d->arch != PINN_ARCH_FOURIER && d->arch != PINN_ARCH_FEEDFORWARD && d->arch != PINN_ARCH_SIREN) return false;
-  if (d->flags & (PINN_FLAG_LAYER_NORM | PINN_FLAG_DETERMINISTIC | PINN_FLAG_LAYER_MAJOR)) return false;
+  if (d->flags & (PINN_FLAG_LAYER_NORM | PINN_FLAG_LAYER_MAJOR)) return false;
   NetDev n;
   memset(&n, 0, sizeof(n));
   n.din = d->input_dim;
@@ -141,6 +141,62 @@ static bool build_wide(const PinnNetDesc* d, const float* const* w, float* const
   n.hmax = hmax;
   *out = n;
   return true;
+}
+
+// ---- deterministic mode of the fused kernel -------------------------------------------------------------------------
+// Every gradient / loss pointer of the NetDev is redirected into row 0 of a [grid][stride] slab in the workspace;
+// workgroup b adds into row b with plain (non-atomic) adds, and this kernel then sums the rows of every element in
+// workgroup order and adds the total to the caller's tensor: two launches on the same inputs give identical bits.
+struct DetTable {
+  int n;
+  float* user[2 * PINN_MAX_LINEAR + 8];
+  unsigned off[2 * PINN_MAX_LINEAR + 8], cnt[2 * PINN_MAX_LINEAR + 8];
+  unsigned stride;
+};
+
+__global__ void wide_det_reduce(const DetTable tab, const float* slab, int rows) {
+  const unsigned it = blockIdx.y;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < tab.cnt[it]; e += gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int b = 0; b < rows; ++b) s += slab[(size_t)b * tab.stride + tab.off[it] + e];
+    tab.user[it][e] += s;
+  }
+}
+
+// redirect one accumulation target into the slab; returns the slab pointer (row 0)
+static float* det_slot(DetTable& t, float* slab, float* user, unsigned count) {
+  if (!user) return nullptr;
+  const int i = t.n++;
+  t.user[i] = user;
+  t.off[i] = t.stride;
+  t.cnt[i] = count;
+  t.stride += (count + 3u) & ~3u;
+  return slab + t.off[i];
+}
+
+// all targets of a NetDev (and the loss sum) -> slab; `slab` may be null for sizing (only t.stride is then meaningful)
+static void det_redirect(NetDev& n, float*& loss_sum, float* slab, DetTable& t) {
+  memset(&t, 0, sizeof(t));
+  static float dummy;
+  float* base = slab ? slab : &dummy;
+  auto slot = [&](float*& p, unsigned count, bool sizing_always) {
+    if (slab) p = det_slot(t, base, p, count);
+    else if (p || sizing_always) t.stride += (count + 3u) & ~3u;
+  };
+  // sizing queries have no pointers: count every target the descriptor can have
+  const bool sizing = slab == nullptr;
+  if (n.enc == ENC_LINEAR) {
+    slot(n.d_encW, (unsigned)(n.enc_out * n.din), sizing);
+    slot(n.d_encb, (unsigned)n.enc_out, sizing);
+  }
+  for (int l = 0; l < n.n_layers; ++l) {
+    slot(n.layer[l].dW, (unsigned)(n.layer[l].out_dim * n.layer[l].ld), sizing);
+    slot(n.layer[l].db, (unsigned)n.layer[l].out_dim, sizing);
+  }
+  slot(n.dw_out, (unsigned)n.h_last, sizing);
+  slot(n.db_out, 1u, sizing);
+  slot(loss_sum, 1u, sizing);
+  if (t.stride == 0) t.stride = 4;
 }
 
 static int check_orders(int nt, int nx) {
@@ -244,16 +300,41 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
 #ifdef PINN_STAMPS
     a.stamps = g_stamps;
 #endif
+    const bool det = (net->flags & PINN_FLAG_DETERMINISTIC) != 0;
+    const size_t tape_floats = bwd ? (size_t)jet_tape_floats_per_wg(K, a.net.n_layers, 1) * grid : 0;
+    size_t need = tape_floats * sizeof(float);
+    DetTable dt;
+    dt.n = 0;
+    if (det) {
+      NetDev probe = a.net;
+      float* lprobe = a.loss_sum;
+      det_redirect(probe, lprobe, nullptr, dt);  // sizing pass: the same stride pinn_workspace_bytes reports
+      need += (size_t)dt.stride * grid * sizeof(float);
+    }
+    if (need > 0 && (!workspace || ws_bytes < need))
+      return fail(PINN_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
+    if (need > 0 && (reinterpret_cast<uintptr_t>(workspace) & 15)) return fail(PINN_ERR_MISALIGNED, "workspace is not 16-byte aligned");
     if (bwd) {
       a.tape_stride = jet_tape_floats_per_wg(K, a.net.n_layers, 1);
-      const size_t need = (size_t)a.tape_stride * sizeof(float) * grid;
-      if (need > 0 && (!workspace || ws_bytes < need))
-        return fail(PINN_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
-      if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(PINN_ERR_MISALIGNED, "workspace is not 16-byte aligned");
       a.tape = static_cast<float*>(workspace);
     }
-    const hipError_t e = dispatch_wide(nt, nx, a, bwd, grid, static_cast<hipStream_t>(stream));
+    float* slab = nullptr;
+    if (det) {
+      const unsigned stride = dt.stride;
+      slab = static_cast<float*>(workspace) + tape_floats;
+      det_redirect(a.net, a.loss_sum, slab, dt);
+      dt.stride = stride;  // rows are as wide as the sizing pass said, whatever subset of targets this call has
+      a.det_stride = stride;
+      const hipError_t em = hipMemsetAsync(slab, 0, (size_t)stride * grid * sizeof(float), static_cast<hipStream_t>(stream));
+      if (em != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)em, hipGetErrorString(em));
+    }
+    hipError_t e = dispatch_wide(nt, nx, a, bwd, grid, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)e, hipGetErrorString(e));
+    if (det && dt.n > 0) {
+      hipLaunchKernelGGL(wide_det_reduce, dim3(32, dt.n), dim3(256), 0, static_cast<hipStream_t>(stream), dt, slab, grid);
+      e = hipGetLastError();
+      if (e != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)e, hipGetErrorString(e));
+    }
     return PINN_OK;
   }
   lm::CallArgs c;
@@ -335,8 +416,15 @@ size_t pinn_workspace_bytes(const PinnNetDesc* net, int64_t N, int32_t time_orde
   const bool bwd = backward != 0;
   NetDev n;
   if (use_wide(net, nullptr, nullptr, K, bwd, &n)) {
-    if (!bwd) return 0;
-    return (size_t)jet_tape_floats_per_wg(K, n.n_layers, 1) * sizeof(float) * (size_t)wide_grid(n, K, N, true);
+    const size_t grid = (size_t)wide_grid(n, K, N, bwd);
+    size_t bytes = bwd ? (size_t)jet_tape_floats_per_wg(K, n.n_layers, 1) * sizeof(float) * grid : 0;
+    if (net->flags & PINN_FLAG_DETERMINISTIC) {
+      DetTable dt;
+      float* lprobe = nullptr;
+      det_redirect(n, lprobe, nullptr, dt);
+      bytes += (size_t)dt.stride * grid * sizeof(float);
+    }
+    return bytes;
   }
   return lm::lm_workspace_bytes(net, N, time_order, space_order, bwd, (net->flags & PINN_FLAG_DETERMINISTIC) != 0);
 }
