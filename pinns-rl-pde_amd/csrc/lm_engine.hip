@@ -52,7 +52,7 @@ __global__ void lm_unpack_kernel(const PackTable tab, const float* packed_grad) 
 // H_p x H_p parameters) and maps the merged gradient back afterwards:
 //   dW_p = G W_v^T + g b_v^T,  dW_v = W_p^T G,  db_v = W_p^T g,  db_p = g        (G = dL/dW_pv, g = dL/db_pv)
 // One thread per output element, fixed summation order: deterministic.  Two of the twelve GEMM launches per layer and
-// one record round trip go away (C5: 113 -> 108 ms).
+// one record round trip go away (C5: 113 -> 105 ms).
 struct MergeItem {
   unsigned wp, bp, wv, bv, wm, bm;  // offsets in the packed block
   int Hp;
