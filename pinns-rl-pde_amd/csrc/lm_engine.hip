@@ -436,6 +436,7 @@ struct Layout {
   size_t params = 0, grads = 0, U = 0;
   size_t V[kMaxNodes], Y[kMaxNodes], Vh = 0;
   size_t Zbar[kMaxNodes], Vbar[kMaxNodes], Pbar[kMaxNodes + 1];  // Pbar[m]: skip cotangent produced by node m's prologue (kMaxNodes = head)
+  size_t Stats[kMaxNodes + 1];  // LayerNorm prologues: per-point sums kept by the forward launch ([tile][2 K][32]); 0 = none
   size_t partial = 0, partial_floats = 0, det = 0;
   size_t total = 0;          // floats
 };
@@ -533,7 +534,18 @@ void make_layout(const Program& P, long long N, int K, bool bwd, bool determinis
   }
   L.Vh = o;
   o += rec_floats(ct, K, P.head.H);
+  for (int m = 0; m <= kMaxNodes; ++m) L.Stats[m] = 0;
   if (bwd) {
+    o = (o + 3) & ~(size_t)3;
+    for (int m = 0; m < P.n_nodes; ++m)
+      if (P.node[m].pro.ln_g >= 0) {
+        L.Stats[m] = o;
+        o += (size_t)ct * 2 * K * kT;
+      }
+    if (P.head.ln_g >= 0) {
+      L.Stats[kMaxNodes] = o;
+      o += (size_t)ct * 2 * K * kT;
+    }
     for (int m = 0; m < P.n_nodes; ++m) {
       L.Zbar[m] = o;
       o += rec_floats(ct, K, P.node[m].Hout);
@@ -772,8 +784,9 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
   const long long ntiles = (c.N + kT - 1) / kT;
   const int cus = num_cus();
 
-  auto fill_ew = [&](EwArgs& a, const Prologue& pro, long long ct, long long p_base) {
+  auto fill_ew = [&](EwArgs& a, const Prologue& pro, long long ct, long long p_base, int self) {  // self: node index, kMaxNodes = head
     memset(&a, 0, sizeof(a));
+    a.stats = (c.bwd && L.Stats[self]) ? ws + L.Stats[self] : nullptr;
     a.H = pro.H;
     a.Hp = round32(pro.H);
     const int fpt = fpt_for(a.Hp);
@@ -814,7 +827,7 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       const Node& nd = P.node[m];
       if (!nd.pro.identity()) {
         EwArgs a;
-        const int fpt = fill_ew(a, nd.pro, ct, p_base);
+        const int fpt = fill_ew(a, nd.pro, ct, p_base, m);
         a.V = ws + L.V[m];
         if (nd.pro.src_kind == SRC_COORDS_FOURIER) LM_CHECK(launch_ew(c.nt, c.nx, a, false, -2, fpt, ew_grid(ct), st));
         else LM_CHECK(launch_ew(c.nt, c.nx, a, false, nd.pro.act, fpt, ew_grid(ct), st));
@@ -834,7 +847,7 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
     }
     {
       EwArgs a;
-      const int fpt = fill_ew(a, P.head, ct, p_base);
+      const int fpt = fill_ew(a, P.head, ct, p_base, kMaxNodes);
       a.V = ws + L.Vh;
       if (P.head.src_kind == SRC_COORDS_FOURIER) LM_CHECK(launch_ew(c.nt, c.nx, a, false, -2, fpt, ew_grid(ct), st));
       else LM_CHECK(launch_ew(c.nt, c.nx, a, false, P.head.act, fpt, ew_grid(ct), st));
@@ -895,7 +908,7 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       const bool needs = pro.src_kind == SRC_REC || (pro.src_kind == SRC_COORDS_LINEAR) || pro.ln_g >= 0 || pro.skip_node >= 0;
       if (!needs) return PINN_OK;  // Fourier features straight from the coordinates: nothing upstream to differentiate
       EwArgs a;
-      const int fpt = fill_ew(a, pro, ct, p_base);
+      const int fpt = fill_ew(a, pro, ct, p_base, self);
       a.Vbar = vbar;
       if (!vbar) {
         a.U = ws + L.U;

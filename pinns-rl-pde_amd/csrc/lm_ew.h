@@ -60,6 +60,8 @@ struct EwArgs {
   float* d_encW;        // [Hp][4]
   float* d_encb;
   float* det_partial;   // deterministic mode: per-workgroup partials [grid][7][1024] instead of float atomics
+  float* stats;         // LayerNorm prologues: [tile][2 K][32] per-point sums (K stream sums, then K second-moment sums)
+                        // written by the forward launch and re-read by the reverse one (saves two block reductions)
 };
 
 // Record access: element (row, point n) of this thread's feature group lives at tile_base + row * 32 floats + tid * 4
@@ -142,10 +144,47 @@ struct LnPoint {
 // stream index of (direction offset lo, order j): j == 0 is the value stream
 __device__ __forceinline__ constexpr int sidx(int lo, int j) { return j == 0 ? 0 : lo + j - 1; }
 
+// second-moment sums -> per-point statistics (shared by the forward pass and the reverse pass that re-reads the sums)
+template <int NT, int NX>
+__device__ __forceinline__ void ln_point_from_moments(const float (&m)[1 + NT + NX], float invH, float eps, LnPoint<NT, NX>& S) {
+  rsqrt_derivs(m[0] * invH + eps, S.g);
+  S.r0 = S.g[0];
+  if constexpr (NT > 0) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) S.t.v[k] = m[1 + k] * invH;
+    dir_fwd<NT>(S.g, S.t.v, S.t.r);
+  }
+  if constexpr (NX > 0) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) S.x.v[k] = m[1 + NT + k] * invH;
+    dir_fwd<NX>(S.g, S.x.v, S.x.r);
+  }
+}
+
+// The reverse pass: the sums the forward launch kept -> centred streams and statistics, no reduction.
+template <int NT, int NX, int FPT>
+__device__ __forceinline__ void ln_stats_restore(float (&c)[FPT][1 + NT + NX], const bool (&valid)[FPT], int H, float eps,
+                                                 LnPoint<NT, NX>& S, const float* stats_in, int ln) {
+  constexpr int K = 1 + NT + NX;
+  const float invH = 1.0f / (float)H;
+  float q[K], m[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) {
+    q[s] = stats_in[s * kT + ln];
+    m[s] = stats_in[(K + s) * kT + ln];
+  }
+#pragma unroll
+  for (int i = 0; i < FPT; ++i)
+#pragma unroll
+    for (int s = 0; s < K; ++s) c[i][s] = valid[i] ? c[i][s] - q[s] * invH : 0.0f;
+  ln_point_from_moments<NT, NX>(m, invH, eps, S);
+}
+
 // c (centred, zero on padding features) -> statistics.  Two block reductions.
 template <int NT, int NX, int FPT>
 __device__ __forceinline__ void ln_stats(float (&c)[FPT][1 + NT + NX], const bool (&valid)[FPT], int H, float eps,
-                                         LnPoint<NT, NX>& S, float* red, int& slot, int nwaves, int wave, int tid, int ln) {
+                                         LnPoint<NT, NX>& S, float* red, int& slot, int nwaves, int wave, int tid, int ln,
+                                         float* stats_out) {
   constexpr int K = 1 + NT + NX;
   const float invH = 1.0f / (float)H;
   float q[K];
@@ -157,6 +196,10 @@ __device__ __forceinline__ void ln_stats(float (&c)[FPT][1 + NT + NX], const boo
     q[s] = p;
   }
   block_sum<K>(q, red, slot, nwaves, wave, tid, ln);
+  if (stats_out && tid < kPT) {  // one lane per point keeps the sums for the reverse sweep
+#pragma unroll
+    for (int s = 0; s < K; ++s) stats_out[s * kT + ln] = q[s];
+  }
 #pragma unroll
   for (int i = 0; i < FPT; ++i)
 #pragma unroll
@@ -178,18 +221,11 @@ __device__ __forceinline__ void ln_stats(float (&c)[FPT][1 + NT + NX], const boo
         m[sidx(1 + NT, k)] = fmaf((float)binom(k, j) * c[i][sidx(1 + NT, j)], c[i][sidx(1 + NT, k - j)], m[sidx(1 + NT, k)]);
   }
   block_sum<K>(m, red, slot, nwaves, wave, tid, ln);
-  rsqrt_derivs(m[0] * invH + eps, S.g);
-  S.r0 = S.g[0];
-  if constexpr (NT > 0) {
+  if (stats_out && tid < kPT) {
 #pragma unroll
-    for (int k = 0; k < NT; ++k) S.t.v[k] = m[1 + k] * invH;
-    dir_fwd<NT>(S.g, S.t.v, S.t.r);
+    for (int s = 0; s < K; ++s) stats_out[(K + s) * kT + ln] = m[s];
   }
-  if constexpr (NX > 0) {
-#pragma unroll
-    for (int k = 0; k < NX; ++k) S.x.v[k] = m[1 + NT + k] * invH;
-    dir_fwd<NX>(S.g, S.x.v, S.x.r);
-  }
+  ln_point_from_moments<NT, NX>(m, invH, eps, S);
 }
 
 // yhat jets of one element from its centred streams
@@ -453,7 +489,9 @@ __global__ __launch_bounds__(1024) void lm_ew_fwd(const EwArgs a) {
     float zc[FPT][K];
     LnPoint<NT, NX> S;
     load_source<NT, NX, FPT>(a, rec_off, voff, goff, xin, zc);
-    if constexpr (LN) ln_stats<NT, NX, FPT>(zc, valid, a.H, a.eps, S, red, slot, nwaves, wave, tid, n);
+    if constexpr (LN)
+      ln_stats<NT, NX, FPT>(zc, valid, a.H, a.eps, S, red, slot, nwaves, wave, tid, n,
+                            a.stats ? a.stats + (unit >> 1) * (2LL * K * kT) + (unit & 1) * kPT : nullptr);
     float* out = a.V + rec_off;
     const float* skip_base = a.skip ? a.skip + rec_off : nullptr;
 #pragma unroll
@@ -521,7 +559,10 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
         for (int s = 0; s < K; ++s) pb[i][s] = w * ub[s];
       }
     }
-    if constexpr (LN) ln_stats<NT, NX, FPT>(zc, valid, a.H, a.eps, S, red, slot, nwaves, wave, tid, n);
+    if constexpr (LN) {
+      if (a.stats) ln_stats_restore<NT, NX, FPT>(zc, valid, a.H, a.eps, S, a.stats + (unit >> 1) * (2LL * K * kT) + (unit & 1) * kPT, n);
+      else ln_stats<NT, NX, FPT>(zc, valid, a.H, a.eps, S, red, slot, nwaves, wave, tid, n, nullptr);
+    }
     const float* skip_base = a.skip ? a.skip + rec_off : nullptr;
 #pragma unroll
     for (int i = 0; i < FPT; ++i) {
