@@ -74,6 +74,16 @@ __device__ __forceinline__ float rec_ld(const float* tile_base, int row, unsigne
 __device__ __forceinline__ void rec_st(float* tile_base, int row, unsigned voff, float v) {
   *reinterpret_cast<float*>(reinterpret_cast<char*>(tile_base + (long long)row * kT) + voff) = v;
 }
+// A kernel-argument pointer the optimizer may not reason about across loop iterations.  The element-wise kernels carry
+// several rarely-taken source / head paths whose per-lane addresses (argument pointer + lane offset + row) are loop
+// invariant; hoisted out of the unit loop they cost two VGPRs each for the whole kernel and pushed the LayerNorm adjoint
+// 45 registers into scratch.  Laundered inside the loop body, the address is rebuilt where it is used.
+template <typename T>
+__device__ __forceinline__ T* in_loop(T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 // per-feature parameter vector: element f = g + G i  ->  base + G i floats (uniform) + 4 g bytes (lane)
 __device__ __forceinline__ float vec_ld(const float* base, int row, unsigned goff) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + row) + goff);
@@ -252,7 +262,7 @@ __device__ __forceinline__ void ln_yhat(const float (&c)[1 + NT + NX], const LnP
 // Out: pb <- cotangent of the pre-LayerNorm jets; dgamma / dbeta contributions per element in dg / dbt.
 template <int NT, int NX, int FPT>
 __device__ __forceinline__ void ln_backward(const float (&c)[FPT][1 + NT + NX], float (&pb)[FPT][1 + NT + NX],
-                                            const bool (&valid)[FPT], const float* ln_g, int G, unsigned goff, float* pacc_g,
+                                            const bool (&valid)[FPT], const float (&gamv)[FPT], int G, float* pacc_g,
                                             float* pacc_b, int g, int H, const LnPoint<NT, NX>& S, float* red, int& slot,
                                             int nwaves, int wave, int tid, int ln) {
   constexpr int K = 1 + NT + NX;
@@ -275,9 +285,8 @@ __device__ __forceinline__ void ln_backward(const float (&c)[FPT][1 + NT + NX], 
         pacc_b[g + G * i] += s1;
       }
     }
-    const float gam = vec_ld(ln_g, G * i, goff);
 #pragma unroll
-    for (int s = 0; s < K; ++s) pb[i][s] = valid[i] ? gam * pb[i][s] : 0.0f;  // now yhat-bar
+    for (int s = 0; s < K; ++s) pb[i][s] = valid[i] ? gamv[i] * pb[i][s] : 0.0f;  // now yhat-bar
     rb[0] = fmaf(c[i][0], pb[i][0], rb[0]);
 #pragma unroll
     for (int k = 1; k <= NT; ++k)
@@ -356,10 +365,12 @@ __device__ __forceinline__ void load_source(const EwArgs& a, long long rec_off, 
 #pragma unroll
       for (int s = 0; s < K; ++s) z[i][s] = rec_ld(base, s * a.Hp + a.G * i, voff);
   } else if (a.src_kind == SRC_COORDS_LINEAR) {
+    const float* encW = in_loop(a.encW);
+    const float* encb = in_loop(a.encb);
 #pragma unroll
     for (int i = 0; i < FPT; ++i) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.encW + 4 * a.G * i) + 4u * goff);  // zero beyond din / H
-      float v = vec_ld(a.encb, a.G * i, goff);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(encW + 4 * a.G * i) + 4u * goff);  // zero beyond din / H
+      float v = vec_ld(encb, a.G * i, goff);
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) v = fmaf(xin[cc], w[cc], v);
 #pragma unroll
@@ -380,27 +391,26 @@ __device__ __forceinline__ void load_coords(const EwArgs& a, long long unit, int
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) xin[cc] = 0.0f;
   if (a.src_kind != SRC_REC && ok) {
+    const float* xs = in_loop(a.x);
+    const float* ts = in_loop(a.t);
 #pragma unroll
     for (int cc = 0; cc < 3; ++cc)
-      if (cc < a.din - 1) xin[cc] = a.x[p * (a.din - 1) + cc];
+      if (cc < a.din - 1) xin[cc] = xs[p * (a.din - 1) + cc];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc)
-      if (cc == a.din - 1) xin[cc] = a.t[p];
+      if (cc == a.din - 1) xin[cc] = ts[p];
   }
 }
 
 // pre-activation jets p of element i: zc holds the source jets, or — with a LayerNorm — their centred streams
 template <int NT, int NX, int FPT, bool LN>
-__device__ __forceinline__ void elem_pre(const EwArgs& a, const float* skip_base, int row, unsigned voff, unsigned goff,
-                                         const float (&zc)[1 + NT + NX], const LnPoint<NT, NX>& S, float& gam,
-                                         float (&p)[1 + NT + NX]) {
+__device__ __forceinline__ void elem_pre(const EwArgs& a, const float* skip_base, int row, unsigned voff, float gam, float bet,
+                                         const float (&zc)[1 + NT + NX], const LnPoint<NT, NX>& S, float (&p)[1 + NT + NX]) {
   constexpr int K = 1 + NT + NX;
-  gam = 0.0f;
   if constexpr (LN) {
-    gam = vec_ld(a.ln_g, row, goff);
     float y[K];
     ln_yhat<NT, NX>(zc, S, y);
-    p[0] = fmaf(gam, y[0], vec_ld(a.ln_b, row, goff));
+    p[0] = fmaf(gam, y[0], bet);
 #pragma unroll
     for (int s = 1; s < K; ++s) p[s] = gam * y[s];
   } else {
@@ -477,6 +487,15 @@ __global__ __launch_bounds__(1024) void lm_ew_fwd(const EwArgs a) {
   bool valid[FPT];
 #pragma unroll
   for (int i = 0; i < FPT; ++i) valid[i] = g + a.G * i < a.H;
+  // LayerNorm scale / shift of this thread's features: loop-invariant, kept in registers.  Re-loading them per unit
+  // looked cheaper, but the compiler hoists the per-lane 64-bit ADDRESSES out of the loop instead (two registers per
+  // value) and spilled them: 36 scratch loads per thread and unit in the LayerNorm adjoint.
+  float gamv[FPT], betv[FPT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    gamv[i] = LN ? vec_ld(a.ln_g, a.G * i, goff) : 0.0f;
+    betv[i] = LN ? vec_ld(a.ln_b, a.G * i, goff) : 0.0f;
+  }
   for (long long uu = 2LL * blockIdx.x; uu < 2 * a.ntiles; uu += (uu & 1) ? 2LL * gridDim.x - 1 : 1) {
     // both 16-point halves of a tile back to back in the SAME workgroup: a 128-byte record row is then fetched from HBM
     // once (the second half hits this CU's caches) and its two 64-byte stores merge; with the halves on neighbouring
@@ -496,8 +515,8 @@ __global__ __launch_bounds__(1024) void lm_ew_fwd(const EwArgs a) {
     const float* skip_base = a.skip ? a.skip + rec_off : nullptr;
 #pragma unroll
     for (int i = 0; i < FPT; ++i) {
-      float p[K], v[K], gam;
-      elem_pre<NT, NX, FPT, LN>(a, skip_base, a.G * i, voff, goff, zc[i], S, gam, p);
+      float p[K], v[K];
+      elem_pre<NT, NX, FPT, LN>(a, skip_base, a.G * i, voff, gamv[i], betv[i], zc[i], S, p);
       if (a.has_act) {
         act_fwd<ACT, NT, NX>(a.act_param, p, v);
       } else {
@@ -524,6 +543,15 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
   bool valid[FPT];
 #pragma unroll
   for (int i = 0; i < FPT; ++i) valid[i] = g + a.G * i < a.H;
+  // LayerNorm scale / shift of this thread's features: loop-invariant, kept in registers.  Re-loading them per unit
+  // looked cheaper, but the compiler hoists the per-lane 64-bit ADDRESSES out of the loop instead (two registers per
+  // value) and spilled them: 36 scratch loads per thread and unit in the LayerNorm adjoint.
+  float gamv[FPT], betv[FPT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    gamv[i] = LN ? vec_ld(a.ln_g, a.G * i, goff) : 0.0f;
+    betv[i] = LN ? vec_ld(a.ln_b, a.G * i, goff) : 0.0f;
+  }
   const bool enc_grad = a.src_kind == SRC_COORDS_LINEAR && a.d_encW;
   if (LN || enc_grad) {
     for (int i = tid; i < kAcc * 1024; i += nthreads) pacc[i] = 0.0f;
@@ -550,24 +578,24 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
         for (int s = 0; s < K; ++s) pb[i][s] = rec_ld(base, s * a.Hp + a.G * i, voff);
     } else {
       float ub[K];
+      const float* U = in_loop(a.U);
+      const float* w_out = in_loop(a.w_out);
 #pragma unroll
-      for (int s = 0; s < K; ++s) ub[s] = a.U[((unit >> 1) * K + s) * kT + (unit & 1) * kPT + n];
+      for (int s = 0; s < K; ++s) ub[s] = U[((unit >> 1) * K + s) * kT + (unit & 1) * kPT + n];
 #pragma unroll
       for (int i = 0; i < FPT; ++i) {
-        const float w = vec_ld(a.w_out, a.G * i, goff);
+        const float w = vec_ld(w_out, a.G * i, goff);
 #pragma unroll
         for (int s = 0; s < K; ++s) pb[i][s] = w * ub[s];
       }
     }
-    if constexpr (LN) {
-      if (a.stats) ln_stats_restore<NT, NX, FPT>(zc, valid, a.H, a.eps, S, a.stats + (unit >> 1) * (2LL * K * kT) + (unit & 1) * kPT, n);
-      else ln_stats<NT, NX, FPT>(zc, valid, a.H, a.eps, S, red, slot, nwaves, wave, tid, n, nullptr);
-    }
+    if constexpr (LN)  // the engine always gives the reverse launch the sums its forward launch kept
+      ln_stats_restore<NT, NX, FPT>(zc, valid, a.H, a.eps, S, a.stats + (unit >> 1) * (2LL * K * kT) + (unit & 1) * kPT, n);
     const float* skip_base = a.skip ? a.skip + rec_off : nullptr;
 #pragma unroll
     for (int i = 0; i < FPT; ++i) {
-      float p[K], gam;
-      elem_pre<NT, NX, FPT, LN>(a, skip_base, a.G * i, voff, goff, zc[i], S, gam, p);
+      float p[K];
+      elem_pre<NT, NX, FPT, LN>(a, skip_base, a.G * i, voff, gamv[i], betv[i], zc[i], S, p);
       if (a.has_act) {
         float zb[K];
         act_bwd<ACT, NT, NX>(a.act_param, p, pb[i], zb);
@@ -576,6 +604,7 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
       }
 #pragma unroll
       for (int s = 0; s < K; ++s) pb[i][s] = valid[i] ? pb[i][s] : 0.0f;
+      __builtin_amdgcn_sched_barrier(0);  // one element at a time: interleaving the four raises the register peak into scratch
     }
     if (a.Pbar) {
       float* out = a.Pbar + rec_off;
@@ -585,7 +614,7 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
         for (int s = 0; s < K; ++s) rec_st(out, s * a.Hp + a.G * i, voff, pb[i][s]);
     }
     if constexpr (LN)
-      ln_backward<NT, NX, FPT>(zc, pb, valid, a.ln_g, a.G, goff, pacc, pacc + 1024, g, a.H, S, red, slot, nwaves, wave, tid, n);
+      ln_backward<NT, NX, FPT>(zc, pb, valid, gamv, a.G, pacc, pacc + 1024, g, a.H, S, red, slot, nwaves, wave, tid, n);
     if (a.src_kind == SRC_REC) {
       if (a.Zbar) {
         float* out = a.Zbar + rec_off;
