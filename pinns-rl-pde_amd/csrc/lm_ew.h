@@ -359,7 +359,7 @@ __device__ __forceinline__ void load_source(const EwArgs& a, long long rec_off, 
                                             float (&z)[FPT][1 + NT + NX]) {
   constexpr int K = 1 + NT + NX;
   if (a.src_kind == SRC_REC) {
-    const float* base = a.srcA + rec_off;
+    const float* base = in_loop(a.srcA) + rec_off;
 #pragma unroll
     for (int i = 0; i < FPT; ++i)
 #pragma unroll
@@ -511,8 +511,8 @@ __global__ __launch_bounds__(1024) void lm_ew_fwd(const EwArgs a) {
     if constexpr (LN)
       ln_stats<NT, NX, FPT>(zc, valid, a.H, a.eps, S, red, slot, nwaves, wave, tid, n,
                             a.stats ? a.stats + (unit >> 1) * (2LL * K * kT) + (unit & 1) * kPT : nullptr);
-    float* out = a.V + rec_off;
-    const float* skip_base = a.skip ? a.skip + rec_off : nullptr;
+    float* out = in_loop(a.V) + rec_off;
+    const float* skip_base = a.skip ? in_loop(a.skip) + rec_off : nullptr;
 #pragma unroll
     for (int i = 0; i < FPT; ++i) {
       float p[K], v[K];
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
     load_source<NT, NX, FPT>(a, rec_off, voff, goff, xin, zc);
     // cotangent of V
     if (a.Vbar) {
-      const float* base = a.Vbar + rec_off;
+      const float* base = in_loop(a.Vbar) + rec_off;
 #pragma unroll
       for (int i = 0; i < FPT; ++i)
 #pragma unroll
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
     }
     if constexpr (LN)  // the engine always gives the reverse launch the sums its forward launch kept
       ln_stats_restore<NT, NX, FPT>(zc, valid, a.H, a.eps, S, a.stats + (unit >> 1) * (2LL * K * kT) + (unit & 1) * kPT, n);
-    const float* skip_base = a.skip ? a.skip + rec_off : nullptr;
+    const float* skip_base = a.skip ? in_loop(a.skip) + rec_off : nullptr;
 #pragma unroll
     for (int i = 0; i < FPT; ++i) {
       float p[K];
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
       __builtin_amdgcn_sched_barrier(0);  // one element at a time: interleaving the four raises the register peak into scratch
     }
     if (a.Pbar) {
-      float* out = a.Pbar + rec_off;
+      float* out = in_loop(a.Pbar) + rec_off;
 #pragma unroll
       for (int i = 0; i < FPT; ++i)
 #pragma unroll
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
       ln_backward<NT, NX, FPT>(zc, pb, valid, gamv, a.G, pacc, pacc + 1024, g, a.H, S, red, slot, nwaves, wave, tid, n);
     if (a.src_kind == SRC_REC) {
       if (a.Zbar) {
-        float* out = a.Zbar + rec_off;
+        float* out = in_loop(a.Zbar) + rec_off;
 #pragma unroll
         for (int i = 0; i < FPT; ++i)
 #pragma unroll
