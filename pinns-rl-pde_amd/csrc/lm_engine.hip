@@ -812,9 +812,13 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
     a.skip = pro.skip_node >= 0 ? ws + L.V[pro.skip_node] : nullptr;
     return fpt;
   };
-  auto ew_grid = [&](long long ct) {  // one workgroup per tile (both of its 16-point halves), two workgroups per CU
+  // Element-wise / head launches: one workgroup per tile (both of its 16-point halves), as many workgroups as fit the
+  // chip at once.  A 1024-thread workgroup of these kernels (65-128 VGPRs) owns a CU; 512-thread ones (widths <= 128)
+  // share it in pairs.  More workgroups than that only repeat the per-workgroup set-up and flush (measured: C3 26.8 ->
+  // 26.7 ms with the exact count, C5 101.7 -> 105.0 ms when its 512-thread launches lose their second workgroup).
+  auto ew_grid = [&](long long ct, int G) {
     long long g = ct;
-    const long long cap = 2LL * cus;
+    const long long cap = (kPT * G > 512 ? 1LL : 2LL) * cus;
     return (int)(g < cap ? g : cap);
   };
 
@@ -829,8 +833,8 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
         EwArgs a;
         const int fpt = fill_ew(a, nd.pro, ct, p_base, m);
         a.V = ws + L.V[m];
-        if (nd.pro.src_kind == SRC_COORDS_FOURIER) LM_CHECK(launch_ew(c.nt, c.nx, a, false, -2, fpt, ew_grid(ct), st));
-        else LM_CHECK(launch_ew(c.nt, c.nx, a, false, nd.pro.act, fpt, ew_grid(ct), st));
+        if (nd.pro.src_kind == SRC_COORDS_FOURIER) LM_CHECK(launch_ew(c.nt, c.nx, a, false, -2, fpt, ew_grid(ct, a.G), st));
+        else LM_CHECK(launch_ew(c.nt, c.nx, a, false, nd.pro.act, fpt, ew_grid(ct, a.G), st));
       }
       GemmArgs g;
       memset(&g, 0, sizeof(g));
@@ -849,8 +853,8 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       EwArgs a;
       const int fpt = fill_ew(a, P.head, ct, p_base, kMaxNodes);
       a.V = ws + L.Vh;
-      if (P.head.src_kind == SRC_COORDS_FOURIER) LM_CHECK(launch_ew(c.nt, c.nx, a, false, -2, fpt, ew_grid(ct), st));
-      else LM_CHECK(launch_ew(c.nt, c.nx, a, false, P.head.act, fpt, ew_grid(ct), st));
+      if (P.head.src_kind == SRC_COORDS_FOURIER) LM_CHECK(launch_ew(c.nt, c.nx, a, false, -2, fpt, ew_grid(ct, a.G), st));
+      else LM_CHECK(launch_ew(c.nt, c.nx, a, false, P.head.act, fpt, ew_grid(ct, a.G), st));
       HeadArgs h;
       memset(&h, 0, sizeof(h));
       h.H = a.H;
@@ -880,7 +884,7 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       h.db_out = gp(P.b_out);
       const bool det = c.deterministic && c.bwd;
       if (det) h.det_partial = ws + L.det;
-      const int hgrid = ew_grid(ct);
+      const int hgrid = ew_grid(ct, h.G);
       LM_CHECK(launch_head(c.nt, c.nx, h, fpt, hgrid, st));
       if (det) {
         SlotReduce r;
@@ -928,7 +932,7 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       }
       const bool has_sums = pro.ln_g >= 0 || (pro.src_kind == SRC_COORDS_LINEAR && a.d_encW);
       if (c.deterministic && has_sums) a.det_partial = ws + L.det;
-      const int egrid = ew_grid(ct);
+      const int egrid = ew_grid(ct, a.G);
       e = launch_ew(c.nt, c.nx, a, true, pro.act, fpt, egrid, st);
       if (e != hipSuccess) return failf(err, en, PINN_ERR_HIP, "HIP error %d: %s (lm_ew_bwd)", (int)e, hipGetErrorString(e));
       if (a.det_partial) {
