@@ -15,7 +15,8 @@
 // all K streams of each in registers — so a record is read once and written once, every global access of a quarter
 // wave is one 64-byte row segment, and at width 256 a thread holds 4 features x K streams (no scratch at four waves
 // per SIMD; with whole 32-point tiles and 8 features per thread the reverse kernel spilled 150-1600 VGPRs).  The
-// per-point feature reductions LayerNorm needs (K means + K moments forward, K + K more in reverse) go through LDS;
+// per-point feature reductions LayerNorm needs (K means + K moments forward — kept per point in a small record so that
+// the reverse launch re-reads instead of re-reducing them — and K + K more in reverse) go through LDS;
 // per-feature sums over points (dgamma, dbeta, encoder gradient) are quarter-wave reductions accumulated in LDS
 // across all units of the workgroup and flushed once.
 #pragma once

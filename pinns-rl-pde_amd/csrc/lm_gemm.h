@@ -3,9 +3,12 @@
 // The operands are plain matrices: a packed zero-padded weight (rows x cols, both multiples of 32) and records whose
 // column blocks are (rows_p x 32) slabs.  Nothing here knows about jets — a stream is just more columns.
 //
-//   lm_gemm<COLS=false>   Y[cb] = W  X[cb] (+ bias on value-stream blocks) (+ add records)      "rows" form
-//   lm_gemm<COLS=true>    Y[cb] = W^T X[cb] (+ add records)                                      "cols" form
-//   lm_gemm_nt            dW += sum_cb Z[cb] V[cb]^T ,  db += sum over value-stream blocks of Z[cb] 1
+//   lm_gemm_wres<NCH, RT> Y[cb] = W  X[cb] (+ bias on value-stream blocks) (+ add records), depth <= 256: the weight
+//                         slice of every wave stays in registers for the whole launch (the engine's default; W^T has its
+//                         own fragment-order copy, so the reverse GEMM is the same kernel)
+//   lm_gemm<COLS=false>   the same for any depth, weight slice streamed from L2                   "rows" form
+//   lm_gemm<COLS=true>    Y[cb] = W^T X[cb] (+ add records) from the untransposed weight          "cols" form (unused now)
+//   lm_gemm_nt / _nt8     dW += sum_cb Z[cb] V[cb]^T ,  db += sum over value-stream blocks of Z[cb] 1
 //
 // lm_gemm: a 256-thread workgroup stages CB = 2 column blocks of the input (up to 256 reduction rows, 72 KB of LDS:
 // two workgroups per CU overlap each other's staging / store phases with MFMA), every wave owns 32-row output tiles,
