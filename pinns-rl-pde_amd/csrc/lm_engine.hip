@@ -979,12 +979,16 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
         if (gx > ncb / 12) gx = ncb / 12;
         if (gx < 1) gx = 1;
         if (gx > 512) gx = 512;
-        const size_t lds = big ? lm_gemm_nt8_lds_bytes() : lm_gemm_nt_lds_bytes();
-        const void* kern = big ? reinterpret_cast<const void*>(lm_gemm_nt8) : reinterpret_cast<const void*>(lm_gemm_nt);
+        static const bool dma_on = [] { const char* e = getenv("PINN_LM_NT8D"); return !(e && atoi(e) == 0); }();  // 0: register-staged nt8
+        const bool dma = dma_on && big && g.z_rows % kNt8 == 0 && g.v_rows % kNt8 == 0;  // the DMA kernel takes complete blocks only
+        const size_t lds = big ? (dma ? lm_gemm_nt8d_lds_bytes() : lm_gemm_nt8_lds_bytes()) : lm_gemm_nt_lds_bytes();
+        const void* kern = big ? (dma ? reinterpret_cast<const void*>(lm_gemm_nt8d) : reinterpret_cast<const void*>(lm_gemm_nt8))
+                               : reinterpret_cast<const void*>(lm_gemm_nt);
         LM_CHECK(allow_lds(kern, lds));
         const size_t stride = (size_t)g.z_rows * g.v_rows + g.z_rows;
         if (c.deterministic) g.partial = ws + L.partial;  // every element of a split's block is stored by exactly one workgroup
-        if (big) hipLaunchKernelGGL(lm_gemm_nt8, dim3(gx, gy, gz), dim3(512), lds, st, g);
+        if (big && dma) hipLaunchKernelGGL(lm_gemm_nt8d, dim3(gx, gy, gz), dim3(512), lds, st, g);
+        else if (big) hipLaunchKernelGGL(lm_gemm_nt8, dim3(gx, gy, gz), dim3(512), lds, st, g);
         else hipLaunchKernelGGL(lm_gemm_nt, dim3(gx, gy, gz), dim3(kThreads), lds, st, g);
         LM_CHECK(hipGetLastError());
         if (c.deterministic) {

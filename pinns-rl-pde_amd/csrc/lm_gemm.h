@@ -680,6 +680,118 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_nt8(const GemmNtArgs a) {
   if (do_db && tid < zn) atomicAdd(a.db + zr0 + tid, dbacc);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// lm_gemm_nt8 with LDS-DMA staging (global_load_lds_dwordx4): the staged Z and V blocks go from HBM straight into
+// LDS — no prefetch registers, no ds_write pass — which leaves room to double-buffer the MFMA operands (the
+// register-staged kernel spends 32 VGPRs on the in-flight block: its MFMA loop alone runs at 80 %, staging adds
+// 20 % on top).  A DMA writes 1 KB per wave-instruction LINEARLY (lane l lands at base + 16 l), so the image is
+// unpadded [row][32 points]; bank conflicts of the row-segment reads are avoided by an XOR swizzle of the 16-byte chunk
+// index with (row >> 1) & 7 — applied to the per-lane SOURCE address of the DMA and to the reads alike (an
+// involution; 16 consecutive rows then cover all 64 banks).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void lm_gemm_nt8d(const GemmNtArgs a) {  // z_rows and v_rows multiples of 256 only
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kBlkF = kNt8 * kT;      // floats per staged block (256 rows x 32 points)
+  constexpr int kImg = 2 * kBlkF;       // Z block then V block
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, ln = tid & 31, lh = (tid >> 5) & 1;
+  const int zr0 = blockIdx.y * kNt8, vc0 = blockIdx.z * kNt8;
+  f32x16 dacc[8];
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dacc[kt][r] = 0.0f;
+  float dbacc = 0.0f;
+  const bool do_db = a.db && blockIdx.z == 0;
+
+  // DMA piece p = 8 u + wave (u = 0..7): pieces 0..31 are 8-row groups of Z, 32..63 of V; lane l -> row 8 p' + (l >> 3),
+  // physical chunk l & 7 = logical chunk ^ ((row >> 1) & 7).  (row >> 1) & 7 depends on the piece only through its
+  // parity = the wave's, so the lane part of every source address is ONE 32-bit offset beside a uniform base.
+  const int rloc = lane >> 3, pc = lane & 7;
+  const unsigned loff = static_cast<unsigned>(rloc * kT + 4 * (pc ^ ((4 * (wave & 1) + (rloc >> 1)) & 7))) * 4u;
+  auto stage = [&](int cb, float* img) {
+    const float* zs = a.Z + ((long long)cb * a.z_rows + zr0) * kT;
+    const float* vs = a.V + ((long long)cb * a.v_rows + vc0) * kT;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int p = 8 * u + wave;
+      const float* base = uniform_ptr((u < 4 ? zs : vs) + (64 * (u & 3) + 8 * wave) * kT);  // piece p' = 8 (u & 3) + wave
+      float* dst = img + p * 256;  // 1 KB per piece, wave-uniform
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + loff),
+                                       (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+    }
+  };
+
+  const int sw = (ln >> 1) & 7;  // read-side swizzle of this lane's rows (Z row wave * 32 + ln, V rows kt * 32 + ln)
+  int buf = 0;
+  int cb = blockIdx.x;
+  if (cb < a.ncb) stage(cb, smem);
+  __syncthreads();
+  for (; cb < a.ncb; cb += gridDim.x) {
+    const int nxt = cb + gridDim.x;
+    const float* img = smem + buf * kImg;
+    if (nxt < a.ncb) stage(nxt, smem + (buf ^ 1) * kImg);  // lands under the MFMAs below
+    if (do_db && (cb % a.K) == 0 && tid < kNt8) {
+      const f32x4* row = reinterpret_cast<const f32x4*>(img + tid * kT);
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 v = row[q];
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      dbacc += s;
+    }
+    {
+      const float* zrow = img + (wave * 32 + ln) * kT;
+      const float* arow = img + kBlkF + ln * kT;
+      f32x4 zc, zn4, ac[8], an[8];
+      auto load_ops = [&](int g, f32x4& z, f32x4 (&av)[8]) {
+        const int off = ((2 * g + lh) ^ sw) * 4;
+        z = *reinterpret_cast<const f32x4*>(zrow + off);
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) av[kt] = *reinterpret_cast<const f32x4*>(arow + kt * 32 * kT + off);
+      };
+      load_ops(0, zc, ac);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g + 1 < 4) load_ops(g + 1, zn4, an);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int kt = 0; kt < 8; ++kt) dacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zc[i], ac[kt][i], dacc[kt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < 4) {
+          zc = zn4;
+#pragma unroll
+          for (int kt = 0; kt < 8; ++kt) ac[kt] = an[kt];
+        }
+      }
+    }
+    __syncthreads();  // drains this stage's DMA (vmcnt) and frees the buffer just read
+    buf ^= 1;
+  }
+  if (a.partial) {
+    float* P = a.partial + (long long)blockIdx.x * ((long long)a.z_rows * a.v_rows + a.z_rows);
+    float* base = P + (long long)(zr0 + wave * 32 + 4 * lh) * a.v_rows + vc0 + ln;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) base[(long long)((r & 3) + 8 * (r >> 2)) * a.v_rows + kt * 32] = dacc[kt][r];
+    if (do_db && tid < kNt8) P[(long long)a.z_rows * a.v_rows + zr0 + tid] = dbacc;
+    return;
+  }
+  float* base = a.dW + (long long)(zr0 + wave * 32 + 4 * lh) * a.v_rows + vc0 + ln;
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(base + (long long)((r & 3) + 8 * (r >> 2)) * a.v_rows + kt * 32, dacc[kt][r]);
+  if (do_db && tid < kNt8) atomicAdd(a.db + zr0 + tid, dbacc);
+}
+
+inline size_t lm_gemm_nt8d_lds_bytes() { return sizeof(float) * (size_t)2 * 2 * kNt8 * kT; }
+
 inline size_t lm_gemm_nt8_lds_bytes() { return sizeof(float) * (size_t)2 * 2 * kNt8 * kTP; }
 
 // deterministic mode: out[i] += sum over splits (fixed order) of partial[s][i]
