@@ -281,11 +281,11 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
   constexpr int CG = 8 / RT;
   constexpr int SB = 2 * CG;                      // column blocks per stage
   constexpr int DEPTH = 32 * NCH;
-  constexpr int kBlk = DEPTH * kTP;               // floats per staged block
-  constexpr int kQuads = SB * DEPTH * 8;          // 16-byte words per stage
-  constexpr int kPre = kQuads / kWresThreads;     // per thread (8 at depth 256 / SB 2)
-  static_assert(kQuads % kWresThreads == 0, "stage must divide over the workgroup");
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][SB][DEPTH][kTP]
+  constexpr int kBlk = DEPTH * kT;                // floats per staged block: unpadded rows, the image of an LDS-DMA copy
+  constexpr int kPieces = SB * DEPTH / 8;         // 1 KB DMA pieces (8 rows) per stage
+  constexpr int kPpw = kPieces / 8;               // per wave (8 at depth 256 / SB 2)
+  static_assert(kPieces % 8 == 0, "stage must divide over the eight waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][SB][DEPTH][32]
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = tid & 31, lh = (tid >> 5) & 1;
@@ -304,31 +304,25 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
     for (int ch = 0; ch < NCH; ++ch) ld_rows(w[ch], wt, lane_off, ch);
   }
 
-  static_assert((DEPTH * 8) % kWresThreads == 0, "a stage word row must not straddle two column blocks");
-  f32x4 pre[kPre];
-  const unsigned toff = static_cast<unsigned>(tid) * 16u;
-  auto fetch = [&](int q) {  // word u * 512 + tid of the stage: block and first word are compile-time, the base is uniform
+  // Staging by LDS-DMA (global_load_lds_dwordx4): a column block is DEPTH x 32 contiguous floats in the record and in
+  // the image alike, so a stage is a plain copy in 1 KB pieces, wave w taking pieces w, w + 8, ... — no prefetch
+  // registers, no ds_write pass.  Each half wave of a B-operand read covers one whole 128-byte row: no bank conflicts
+  // without padding.
+  const unsigned loff = static_cast<unsigned>(tid & 63) * 16u;
+  auto stage_piece = [&](int q, int buf, int u) {
     const int cb0 = ((int)blockIdx.x + q * (int)gridDim.x) * SB;
-#pragma unroll
-    for (int u = 0; u < kPre; ++u) {
-      const int c = (u * kWresThreads) / (DEPTH * 8), r0 = (u * kWresThreads) % (DEPTH * 8);
-      const int cb = cb0 + c < a.ncb ? cb0 + c : a.ncb - 1;  // clamped, unconditional (never stored past the end)
-      const float* base = uniform_ptr(a.X + (long long)cb * kT * DEPTH + 4 * r0);
-      pre[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + toff);
-    }
-  };
-  auto stash = [&](int buf) {
-    float* dst = smem + buf * (SB * kBlk) + (tid >> 3) * kTP + 4 * (tid & 7);
-#pragma unroll
-    for (int u = 0; u < kPre; ++u) {
-      const int c = (u * kWresThreads) / (DEPTH * 8), r0 = (u * kWresThreads) % (DEPTH * 8);
-      *reinterpret_cast<f32x4*>(dst + c * kBlk + (r0 >> 3) * kTP) = pre[u];
-    }
+    const int p = 8 * u + wave;
+    const int c = p / (DEPTH / 8), rg = p % (DEPTH / 8);
+    const int cb = cb0 + c < a.ncb ? cb0 + c : a.ncb - 1;  // clamped, unconditional (never stored past the end)
+    const float* base = uniform_ptr(a.X + (long long)cb * kT * DEPTH + rg * 256);
+    float* dst = smem + buf * (SB * kBlk) + c * kBlk + rg * 256;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + loff),
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
   };
 
   if (my_items > 0) {
-    fetch(0);
-    stash(0);
+#pragma unroll
+    for (int u = 0; u < kPpw; ++u) stage_piece(0, 0, u);
   }
   float* sbias = smem + 2 * SB * kBlk;  // this block's 32 RT bias values
   if (tid < 32 * RT) {
@@ -357,20 +351,19 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
         acc_start(acc[c], row_ok && cb < a.ncb && a.bias && (cb % a.K) == 0 ? sbias + 32 * rt : nullptr, lh);
       }
     }
-    const float* col = smem + (q & 1) * (SB * kBlk) + (2 * cg) * kBlk + (4 * lh) * kTP + ln;
+    const float* col = smem + (q & 1) * (SB * kBlk) + (2 * cg) * kBlk + (4 * lh) * kT + ln;
     float bc[4][2], bn[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) bc[i][c] = col[c * kBlk + i * kTP];
+      for (int c = 0; c < 2; ++c) bc[i][c] = col[c * kBlk + i * kT];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         constexpr int last = 32 * NCH - 8;
         const int kn = (32 * ch + 8 * g) < last ? 32 * ch + 8 * (g + 1) : last;  // the final group re-reads itself
-        // the PREVIOUS stage's tiles leave during the first half of this stage's MFMAs (kSt stores per k-group),
-        // the NEXT stage's rows are requested at half time: `prev` and `pre` never live together
+        // the PREVIOUS stage's tiles leave during the first half of this stage's MFMAs (kSt stores per k-group)
         constexpr int kGroupsHalf = 2 * NCH;
         constexpr int kSt = 32 / kGroupsHalf;
         const int gi = 4 * ch + g;
@@ -380,12 +373,14 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
             const int idx = gi * kSt + e, c = idx >> 4, r = idx & 15;
             if (prev_live[c]) *row_ptr(prev_base[c], r) = prev[c][r];
           }
+        } else {  // second half: the next stage's DMA pieces, one per k-group, behind the stores (lands before the barrier)
+          const int u = gi - kGroupsHalf;
+          if (u < kPpw && q + 1 < my_items) stage_piece(q + 1, (q + 1) & 1, u);
         }
-        if (gi == kGroupsHalf && q + 1 < my_items) fetch(q + 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) bn[i][c] = col[c * kBlk + (kn + i) * kTP];
+          for (int c = 0; c < 2; ++c) bn[i][c] = col[c * kBlk + (kn + i) * kT];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -427,7 +422,6 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
 #pragma unroll
       for (int c = 0; c < 2; ++c) prev[c] = acc[c];
     }
-    if (q + 1 < my_items) stash((q + 1) & 1);
     __syncthreads();
   }
 #pragma unroll
@@ -438,7 +432,7 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
     }
 }
 
-inline size_t lm_gemm_wres_lds_bytes(int nch, int rt) { return sizeof(float) * (2u * (2u * (8 / rt)) * (32u * nch) * kTP + 32u * rt); }
+inline size_t lm_gemm_wres_lds_bytes(int nch, int rt) { return sizeof(float) * (2u * (2u * (8 / rt)) * (32u * nch) * kT + 32u * rt); }
 
 inline size_t lm_gemm_lds_bytes(int depth) { return sizeof(float) * (size_t)kCB * (depth < kKC ? depth : kKC) * kTP; }
 
