@@ -217,3 +217,33 @@ def test_arbitrary_widths(arch, pde_name, kw, engine, dev):
     got = torch.cat([by_name[k].flatten().cpu() for k in keys])
     want = torch.cat([g_o[k].flatten() for k in keys])
     assert rel_l2(got, want) <= TOL, f"{rel_l2(got, want):.3e}"
+
+
+def test_deterministic_mode_at_width_256(dev):
+    """PINN_FLAG_DETERMINISTIC through the 256 x 256 weight-gradient kernel (LDS-DMA staging, per-split partial blocks)
+    and the LayerNorm element-wise kernels: two launches bit-identical, equal to the default path to rounding, on a
+    batch large enough for several column blocks per workgroup."""
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import engine as E
+    import oracle as O
+
+    spec = O.ArchSpec(architecture="resnet", input_dim=2, hidden_dim=256, num_layers=2, num_blocks=2)
+    pde = O.PdeSpec(name="allen_cahn", parameters={"epsilon": 0.05})
+    sd = O.init_state_dict(spec, seed=21)
+    torch.manual_seed(22)
+    x, t = O.sample_uniform(pde, 40000)
+    x, t = x.to(dev), t.to(dev)
+    prog, names = program_from_spec(spec, sd, dev)
+    pd = pde_desc_from_spec(pde)
+    N = x.shape[0]
+    ref = E.new_flat_grad(prog, dev)
+    _, s_ref = E.residual_loss_grad(prog, pd, x, t, 1.0 / N, ref)
+    prog.set_deterministic(True)
+    runs = []
+    for _ in range(2):
+        flat = E.new_flat_grad(prog, dev)
+        _, s_ = E.residual_loss_grad(prog, pd, x, t, 1.0 / N, flat)
+        runs.append((flat.clone(), s_.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert rel_l2(runs[0][0].cpu(), ref.cpu()) <= TOL
+    assert abs(float(runs[0][1]) - float(s_ref)) <= TOL * abs(float(s_ref))
