@@ -85,6 +85,11 @@ __device__ __forceinline__ T* in_loop(T* p) {
   return p;
 }
 
+__device__ __forceinline__ int in_loop_i(int v) {  // the same for a uniform integer (row strides: their multiples are addresses too)
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
 // per-feature parameter vector: element f = g + G i  ->  base + G i floats (uniform) + 4 g bytes (lane)
 __device__ __forceinline__ float vec_ld(const float* base, int row, unsigned goff) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + row) + goff);
@@ -97,7 +102,11 @@ __host__ __device__ constexpr int binom(int n, int k) {
 
 // sum over all threads that share this thread's point n (all feature groups); every thread gets the totals.
 // `slot` alternates between two LDS areas so that one barrier per reduction suffices.
-template <int NQ>
+// Barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. an LDS-DMA prefetch in flight; the
+// kernels that keep one across their reductions synchronise with this instead (all waves reach every barrier).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NQ, bool RAW = false>
 __device__ __forceinline__ void block_sum(float (&q)[NQ], float* red, int& slot, int nwaves, int wave, int tid, int n) {
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
@@ -110,7 +119,8 @@ __device__ __forceinline__ void block_sum(float (&q)[NQ], float* red, int& slot,
 #pragma unroll
     for (int i = 0; i < NQ; ++i) area[(wave * kRedQ + i) * kPT + n] = q[i];
   }
-  __syncthreads();
+  if constexpr (RAW) lds_barrier();
+  else __syncthreads();
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     float s = 0.0f;
@@ -261,7 +271,7 @@ __device__ __forceinline__ void ln_yhat(const float (&c)[1 + NT + NX], const LnP
 
 // Adjoint of LayerNorm for this thread's elements.  In: c (centred), pb = cotangent of gamma * yhat + beta.
 // Out: pb <- cotangent of the pre-LayerNorm jets; dgamma / dbeta contributions per element in dg / dbt.
-template <int NT, int NX, int FPT>
+template <int NT, int NX, int FPT, bool RAW = false>
 __device__ __forceinline__ void ln_backward(const float (&c)[FPT][1 + NT + NX], float (&pb)[FPT][1 + NT + NX],
                                             const bool (&valid)[FPT], const float (&gamv)[FPT], int G, float* pacc_g,
                                             float* pacc_b, int g, int H, const LnPoint<NT, NX>& S, float* red, int& slot,
@@ -299,7 +309,7 @@ __device__ __forceinline__ void ln_backward(const float (&c)[FPT][1 + NT + NX], 
       for (int j = 0; j <= k; ++j)
         rb[sidx(1 + NT, k - j)] = fmaf((float)binom(k, j) * c[i][sidx(1 + NT, j)], pb[i][sidx(1 + NT, k)], rb[sidx(1 + NT, k - j)]);
   }
-  block_sum<K>(rb, red, slot, nwaves, wave, tid, ln);
+  block_sum<K, RAW>(rb, red, slot, nwaves, wave, tid, ln);
   // per-point scalars: vbar_k per direction, vbar_0
   float v0b = S.g[1] * rb[0];
   float vbt[NT > 0 ? NT : 1], vbx[NX > 0 ? NX : 1];
@@ -345,7 +355,7 @@ __device__ __forceinline__ void ln_backward(const float (&c)[FPT][1 + NT + NX], 
       mq[s] += pb[i][s];
     }
   }
-  block_sum<K>(mq, red, slot, nwaves, wave, tid, ln);
+  block_sum<K, RAW>(mq, red, slot, nwaves, wave, tid, ln);
 #pragma unroll
   for (int i = 0; i < FPT; ++i)
 #pragma unroll
@@ -666,6 +676,159 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
       }
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm prologue adjoint with the NEXT unit prefetched by LDS-DMA.
+//
+// lm_ew_bwd holds a unit in registers (one 1024-thread workgroup per CU), so nothing overlaps its load, reduce and store
+// phases: 3.2 TB/s where the bare access pattern reaches 4.7.  Here the source and cotangent jets of
+// unit u + 1 (and its saved LayerNorm sums) travel HBM -> LDS by global_load_lds_dwordx4 while unit u is being
+// reduced: 2 K pieces of 1 KB per wave, each 16 half rows of 64 bytes gathered through the per-lane source address
+// into a linear [row][16 points] image.  Barriers inside the unit are LDS-only (lds_barrier), so the DMA stays in
+// flight across them; it is retired with vmcnt(0) just before the unit's final stores, which are then never waited
+// for.  The skip record (ResNet's second prologue only) is still read into registers at the top of a unit.
+// Requirements (checked by the launcher): record source, cotangent record, LayerNorm, K * Hp <= 1024 rows.
+// Dynamic LDS: 2 images of 64 K Hp bytes + 16 half rows of sums + 8 KB of gamma/beta accumulators + 16 KB of partials.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ACT, int NT, int NX, int FPT>
+__global__ __launch_bounds__(1024) void lm_ew_bwd_dma(const EwArgs a) {
+  constexpr int K = 1 + NT + NX;
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int R = K * a.Hp;                      // rows of one record per unit
+  float* zimg = dsm;                           // [R][16]
+  float* pimg = zimg + R * kPT;                // [R][16]
+  float* simg = pimg + R * kPT;                // [16 half rows][16]: the first 2 K are this unit's saved sums
+  float* pacc = simg + 16 * kPT;               // [2][1024]
+  float* red = pacc + 2 * 1024;                // [2][16 waves][8][16]
+  const int tid = threadIdx.x, n = tid & (kPT - 1), g = tid >> 4, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (a.G + 3) >> 2;
+  const int nthreads = kPT * a.G;
+  int slot = 0;
+  const unsigned voff = static_cast<unsigned>(g * kT + n) * 4u, goff = static_cast<unsigned>(g) * 4u;
+  bool valid[FPT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) valid[i] = g + a.G * i < a.H;
+  float gamv[FPT], betv[FPT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    gamv[i] = vec_ld(a.ln_g, a.G * i, goff);
+    betv[i] = vec_ld(a.ln_b, a.G * i, goff);
+  }
+  for (int i = tid; i < 2 * 1024; i += nthreads) pacc[i] = 0.0f;
+
+  // DMA of one unit: pieces 0 .. R/16 - 1 of the source record, the same of the cotangent record, one of the sums
+  const int ppr = R >> 4;  // pieces per record
+  const unsigned lsrc = static_cast<unsigned>((lane >> 2) * kT + (lane & 3) * 4) * 4u;  // half row (lane >> 2), quarter (lane & 3)
+  auto issue = [&](long long unit) {
+    const long long rec_off = (unit >> 1) * (long long)K * a.Hp * kT + (unit & 1) * kPT;
+    for (int p = wave; p < 2 * ppr; p += nwaves) {
+      const bool isz = p < ppr;
+      const int j = isz ? p : p - ppr;
+      const float* base = uniform_ptr((isz ? a.srcA : a.Vbar) + rec_off + (long long)j * 16 * kT);
+      float* dst = (isz ? zimg : pimg) + j * 256;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + lsrc),
+                                       (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+    }
+    if (wave == 0) {  // [tile][2 K][32] sums: 2 K half rows (<= 14), gathered like the others; rows beyond are never read
+      const float* base = uniform_ptr(a.stats + (unit >> 1) * (2LL * K * kT) + (unit & 1) * kPT);
+      const unsigned ls = static_cast<unsigned>(((lane >> 2) < 2 * K ? (lane >> 2) : 2 * K - 1) * kT + (lane & 3) * 4) * 4u;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + ls),
+                                       (__attribute__((address_space(3))) void*)(simg), 16, 0, 0);
+    }
+  };
+
+  const long long first = 2LL * blockIdx.x, last = 2 * a.ntiles;
+  auto next_of = [&](long long uu) { return uu + ((uu & 1) ? 2LL * gridDim.x - 1 : 1); };
+  if (first < last) issue(first);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (long long uu = first; uu < last; uu = next_of(uu)) {
+    const long long unit = uu;
+    const long long rec_off = (unit >> 1) * (long long)K * a.Hp * kT + (unit & 1) * kPT;
+    lds_barrier();  // every wave has retired its pieces of this unit (and zeroed its share of pacc the first time round)
+    const int Hp = in_loop_i(a.Hp), G = in_loop_i(a.G);  // 32 image addresses are NOT loop invariants worth 32 registers
+    float zc[FPT][K], pb[FPT][K];
+    {
+      const float* zl = zimg + g * kPT + n;
+      const float* pl = pimg + g * kPT + n;
+#pragma unroll
+      for (int i = 0; i < FPT; ++i)
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+          zc[i][s] = zl[(s * Hp + G * i) * kPT];
+          pb[i][s] = pl[(s * Hp + G * i) * kPT];
+        }
+    }
+    LnPoint<NT, NX> S;
+    {
+      const float invH = 1.0f / (float)a.H;
+      float q[K], m[K];
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        q[s] = simg[s * kPT + n];
+        m[s] = simg[(K + s) * kPT + n];
+      }
+#pragma unroll
+      for (int i = 0; i < FPT; ++i)
+#pragma unroll
+        for (int s = 0; s < K; ++s) zc[i][s] = valid[i] ? zc[i][s] - q[s] * invH : 0.0f;
+      ln_point_from_moments<NT, NX>(m, invH, a.eps, S);
+    }
+    // the skip record's jets (ordinary loads: requested and consumed BEFORE the next DMA goes out, so that their wait
+    // does not drain it): p = LN(z) gamma + beta + skip, then the activation adjoint
+    const bool has_skip = a.skip != nullptr;
+    {
+      const float* sb = has_skip ? in_loop(a.skip) + rec_off : nullptr;
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) {
+        float p[K];
+        elem_pre<NT, NX, FPT, true>(a, sb, G * i, voff, gamv[i], betv[i], zc[i], S, p);
+        if (a.has_act) {
+          float zb[K];
+          act_bwd<ACT, NT, NX>(a.act_param, p, pb[i], zb);
+#pragma unroll
+          for (int s = 0; s < K; ++s) pb[i][s] = zb[s];
+        }
+#pragma unroll
+        for (int s = 0; s < K; ++s) pb[i][s] = valid[i] ? pb[i][s] : 0.0f;
+      }
+    }
+    lds_barrier();  // all waves have taken their elements out of the images: the next unit may land
+    const long long nxt = next_of(uu);
+    if (nxt < last) issue(nxt);
+    if (a.Pbar) {
+      float* out = in_loop(a.Pbar) + rec_off;
+#pragma unroll
+      for (int i = 0; i < FPT; ++i)
+#pragma unroll
+        for (int s = 0; s < K; ++s) rec_st(out, s * Hp + G * i, voff, pb[i][s]);
+    }
+    ln_backward<NT, NX, FPT, true>(zc, pb, valid, gamv, G, pacc, pacc + 1024, g, a.H, S, red, slot, nwaves, wave, tid, n);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the prefetch (and the Pbar stores) retired; the stores below are not waited for
+    {
+      float* out = in_loop(a.Zbar) + rec_off;
+#pragma unroll
+      for (int i = 0; i < FPT; ++i)
+#pragma unroll
+        for (int s = 0; s < K; ++s) rec_st(out, s * Hp + G * i, voff, pb[i][s]);
+    }
+  }
+  __syncthreads();
+  if (a.det_partial) {  // plain stores; lm_reduce_slots adds them up in workgroup order
+    float* P = a.det_partial + (long long)blockIdx.x * (7 * 1024);
+    for (int i = tid; i < 2 * 1024; i += nthreads) P[i] = pacc[i];
+  } else if (a.d_ln_g) {
+    for (int f = tid; f < a.H; f += nthreads) {
+      atomicAdd(a.d_ln_g + f, pacc[f]);
+      atomicAdd(a.d_ln_b + f, pacc[1024 + f]);
+    }
+  }
+}
+
+inline size_t lm_ew_bwd_dma_lds_bytes(int K, int Hp) { return sizeof(float) * ((size_t)2 * K * Hp * kPT + 16 * kPT + 2 * 1024 + 2 * kMaxWavesEw * kRedQ * kPT); }
+inline bool lm_ew_bwd_dma_ok(const EwArgs& a, int K) {
+  return a.ln_g && a.src_kind == SRC_REC && a.Vbar && a.Zbar && a.stats && K * a.Hp <= 1024 && (a.Hp % 16) == 0;
 }
 
 }  // namespace lm

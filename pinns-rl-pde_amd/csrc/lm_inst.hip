@@ -1,4 +1,6 @@
 // One stream set (PINN_NT, PINN_NX) of the layer-major engine's element-wise and head kernels.
+#include <cstdlib>
+
 #include "lm_engine.h"
 
 #ifndef PINN_NT
@@ -11,9 +13,27 @@ namespace lm {
 #define PINN_CAT2(a, b, c, d) a##b##c##_##d
 #define PINN_NAME(a, b, c) PINN_CAT2(launch_lm_, a, b, c)
 
+static bool ew_dma_on() {  // PINN_LM_EWDMA=0: the register-staged LayerNorm adjoint everywhere (experiments), read once
+  static const bool v = [] {
+    const char* e = getenv("PINN_LM_EWDMA");
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
+
 template <int ACT, int FPT, bool LN>
 static hipError_t launch_ew(const EwArgs& a, bool bwd, int grid, hipStream_t st) {
   const int threads = kPT * a.G;
+  if constexpr (LN && FPT == 4) {
+    constexpr int K = 1 + PINN_NT + PINN_NX;
+    if (bwd && ew_dma_on() && lm_ew_bwd_dma_ok(a, K)) {  // next unit prefetched by LDS-DMA (lm_ew.h)
+      auto kern = lm_ew_bwd_dma<ACT, PINN_NT, PINN_NX, FPT>;
+      const hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern));
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lm_ew_bwd_dma_lds_bytes(K, a.Hp), st, a);
+      return hipGetLastError();
+    }
+  }
   if (bwd) hipLaunchKernelGGL((lm_ew_bwd<ACT, PINN_NT, PINN_NX, FPT, LN>), dim3(grid), dim3(threads), 0, st, a);
   else hipLaunchKernelGGL((lm_ew_fwd<ACT, PINN_NT, PINN_NX, FPT, LN>), dim3(grid), dim3(threads), 0, st, a);
   return hipGetLastError();
