@@ -202,7 +202,7 @@ __device__ __forceinline__ void ln_stats_restore(float (&c)[FPT][1 + NT + NX], c
 }
 
 // c (centred, zero on padding features) -> statistics.  Two block reductions.
-template <int NT, int NX, int FPT>
+template <int NT, int NX, int FPT, bool RAW = false>
 __device__ __forceinline__ void ln_stats(float (&c)[FPT][1 + NT + NX], const bool (&valid)[FPT], int H, float eps,
                                          LnPoint<NT, NX>& S, float* red, int& slot, int nwaves, int wave, int tid, int ln,
                                          float* stats_out) {
@@ -216,7 +216,7 @@ __device__ __forceinline__ void ln_stats(float (&c)[FPT][1 + NT + NX], const boo
     for (int i = 0; i < FPT; ++i) p += valid[i] ? c[i][s] : 0.0f;
     q[s] = p;
   }
-  block_sum<K>(q, red, slot, nwaves, wave, tid, ln);
+  block_sum<K, RAW>(q, red, slot, nwaves, wave, tid, ln);
   if (stats_out && tid < kPT) {  // one lane per point keeps the sums for the reverse sweep
 #pragma unroll
     for (int s = 0; s < K; ++s) stats_out[s * kT + ln] = q[s];
@@ -241,7 +241,7 @@ __device__ __forceinline__ void ln_stats(float (&c)[FPT][1 + NT + NX], const boo
       for (int j = 0; j <= k; ++j)
         m[sidx(1 + NT, k)] = fmaf((float)binom(k, j) * c[i][sidx(1 + NT, j)], c[i][sidx(1 + NT, k - j)], m[sidx(1 + NT, k)]);
   }
-  block_sum<K>(m, red, slot, nwaves, wave, tid, ln);
+  block_sum<K, RAW>(m, red, slot, nwaves, wave, tid, ln);
   if (stats_out && tid < kPT) {
 #pragma unroll
     for (int s = 0; s < K; ++s) stats_out[(K + s) * kT + ln] = m[s];
@@ -689,6 +689,8 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
 // into a linear [row][16 points] image.  Barriers inside the unit are LDS-only (lds_barrier), so the DMA stays in
 // flight across them; it is retired with vmcnt(0) just before the unit's final stores, which are then never waited
 // for.  The skip record (ResNet's second prologue only) is still read into registers at the top of a unit.
+// (The same prefetch in the FORWARD prologue measured no gain — 294 vs 287 us: two reductions are too little work to
+// cover a unit's transfer — so the forward kernel stays register-staged.)
 // Requirements (checked by the launcher): record source, cotangent record, LayerNorm, K * Hp <= 1024 rows.
 // Dynamic LDS: 2 images of 64 K Hp bytes + 16 half rows of sums + 8 KB of gamma/beta accumulators + 16 KB of partials.
 // ---------------------------------------------------------------------------------------------------------------
