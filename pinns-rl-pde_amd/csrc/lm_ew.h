@@ -512,30 +512,33 @@ __global__ __launch_bounds__(1024) void lm_ew_fwd(const EwArgs a) {
     // once (the second half hits this CU's caches) and its two 64-byte stores merge; with the halves on neighbouring
     // workgroups (different XCDs under round-robin dispatch) every line crossed the fabric twice
     const long long unit = uu;
+    EwArgs al = a;  // row strides laundered per unit: their multiples are addresses, and hoisted addresses are registers
+    al.Hp = in_loop_i(a.Hp);
+    al.G = in_loop_i(a.G);
     float xin[4];
     bool ok;
-    load_coords(a, unit, n, xin, ok);
-    const long long rec_off = (unit >> 1) * (long long)K * a.Hp * kT + (unit & 1) * kPT;
+    load_coords(al, unit, n, xin, ok);
+    const long long rec_off = (unit >> 1) * (long long)K * al.Hp * kT + (unit & 1) * kPT;
     float zc[FPT][K];
     LnPoint<NT, NX> S;
-    load_source<NT, NX, FPT>(a, rec_off, voff, goff, xin, zc);
+    load_source<NT, NX, FPT>(al, rec_off, voff, goff, xin, zc);
     if constexpr (LN)
-      ln_stats<NT, NX, FPT>(zc, valid, a.H, a.eps, S, red, slot, nwaves, wave, tid, n,
-                            a.stats ? a.stats + (unit >> 1) * (2LL * K * kT) + (unit & 1) * kPT : nullptr);
-    float* out = in_loop(a.V) + rec_off;
-    const float* skip_base = a.skip ? in_loop(a.skip) + rec_off : nullptr;
+      ln_stats<NT, NX, FPT>(zc, valid, al.H, al.eps, S, red, slot, nwaves, wave, tid, n,
+                            al.stats ? al.stats + (unit >> 1) * (2LL * K * kT) + (unit & 1) * kPT : nullptr);
+    float* out = in_loop(al.V) + rec_off;
+    const float* skip_base = al.skip ? in_loop(al.skip) + rec_off : nullptr;
 #pragma unroll
     for (int i = 0; i < FPT; ++i) {
       float p[K], v[K];
-      elem_pre<NT, NX, FPT, LN>(a, skip_base, a.G * i, voff, gamv[i], betv[i], zc[i], S, p);
-      if (a.has_act) {
-        act_fwd<ACT, NT, NX>(a.act_param, p, v);
+      elem_pre<NT, NX, FPT, LN>(al, skip_base, al.G * i, voff, gamv[i], betv[i], zc[i], S, p);
+      if (al.has_act) {
+        act_fwd<ACT, NT, NX>(al.act_param, p, v);
       } else {
 #pragma unroll
         for (int s = 0; s < K; ++s) v[s] = p[s];
       }
 #pragma unroll
-      for (int s = 0; s < K; ++s) rec_st(out, s * a.Hp + a.G * i, voff, valid[i] ? v[s] : 0.0f);
+      for (int s = 0; s < K; ++s) rec_st(out, s * al.Hp + al.G * i, voff, valid[i] ? v[s] : 0.0f);
     }
   }
 }
@@ -573,43 +576,46 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
     // once (the second half hits this CU's caches) and its two 64-byte stores merge; with the halves on neighbouring
     // workgroups (different XCDs under round-robin dispatch) every line crossed the fabric twice
     const long long unit = uu;
+    EwArgs al = a;  // row strides laundered per unit (see lm_ew_fwd)
+    al.Hp = in_loop_i(a.Hp);
+    al.G = in_loop_i(a.G);
     float xin[4];
     bool ok;
-    load_coords(a, unit, n, xin, ok);
-    const long long rec_off = (unit >> 1) * (long long)K * a.Hp * kT + (unit & 1) * kPT;
+    load_coords(al, unit, n, xin, ok);
+    const long long rec_off = (unit >> 1) * (long long)K * al.Hp * kT + (unit & 1) * kPT;
     float zc[FPT][K], pb[FPT][K];
     LnPoint<NT, NX> S;
-    load_source<NT, NX, FPT>(a, rec_off, voff, goff, xin, zc);
+    load_source<NT, NX, FPT>(al, rec_off, voff, goff, xin, zc);
     // cotangent of V
-    if (a.Vbar) {
-      const float* base = in_loop(a.Vbar) + rec_off;
+    if (al.Vbar) {
+      const float* base = in_loop(al.Vbar) + rec_off;
 #pragma unroll
       for (int i = 0; i < FPT; ++i)
 #pragma unroll
-        for (int s = 0; s < K; ++s) pb[i][s] = rec_ld(base, s * a.Hp + a.G * i, voff);
+        for (int s = 0; s < K; ++s) pb[i][s] = rec_ld(base, s * al.Hp + al.G * i, voff);
     } else {
       float ub[K];
-      const float* U = in_loop(a.U);
-      const float* w_out = in_loop(a.w_out);
+      const float* U = in_loop(al.U);
+      const float* w_out = in_loop(al.w_out);
 #pragma unroll
       for (int s = 0; s < K; ++s) ub[s] = U[((unit >> 1) * K + s) * kT + (unit & 1) * kPT + n];
 #pragma unroll
       for (int i = 0; i < FPT; ++i) {
-        const float w = vec_ld(w_out, a.G * i, goff);
+        const float w = vec_ld(w_out, al.G * i, goff);
 #pragma unroll
         for (int s = 0; s < K; ++s) pb[i][s] = w * ub[s];
       }
     }
     if constexpr (LN)  // the engine always gives the reverse launch the sums its forward launch kept
-      ln_stats_restore<NT, NX, FPT>(zc, valid, a.H, a.eps, S, a.stats + (unit >> 1) * (2LL * K * kT) + (unit & 1) * kPT, n);
-    const float* skip_base = a.skip ? in_loop(a.skip) + rec_off : nullptr;
+      ln_stats_restore<NT, NX, FPT>(zc, valid, al.H, al.eps, S, al.stats + (unit >> 1) * (2LL * K * kT) + (unit & 1) * kPT, n);
+    const float* skip_base = al.skip ? in_loop(al.skip) + rec_off : nullptr;
 #pragma unroll
     for (int i = 0; i < FPT; ++i) {
       float p[K];
-      elem_pre<NT, NX, FPT, LN>(a, skip_base, a.G * i, voff, gamv[i], betv[i], zc[i], S, p);
-      if (a.has_act) {
+      elem_pre<NT, NX, FPT, LN>(al, skip_base, al.G * i, voff, gamv[i], betv[i], zc[i], S, p);
+      if (al.has_act) {
         float zb[K];
-        act_bwd<ACT, NT, NX>(a.act_param, p, pb[i], zb);
+        act_bwd<ACT, NT, NX>(al.act_param, p, pb[i], zb);
 #pragma unroll
         for (int s = 0; s < K; ++s) pb[i][s] = zb[s];
       }
@@ -617,22 +623,22 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
       for (int s = 0; s < K; ++s) pb[i][s] = valid[i] ? pb[i][s] : 0.0f;
       __builtin_amdgcn_sched_barrier(0);  // one element at a time: interleaving the four raises the register peak into scratch
     }
-    if (a.Pbar) {
-      float* out = in_loop(a.Pbar) + rec_off;
+    if (al.Pbar) {
+      float* out = in_loop(al.Pbar) + rec_off;
 #pragma unroll
       for (int i = 0; i < FPT; ++i)
 #pragma unroll
-        for (int s = 0; s < K; ++s) rec_st(out, s * a.Hp + a.G * i, voff, pb[i][s]);
+        for (int s = 0; s < K; ++s) rec_st(out, s * al.Hp + al.G * i, voff, pb[i][s]);
     }
     if constexpr (LN)
-      ln_backward<NT, NX, FPT>(zc, pb, valid, gamv, a.G, pacc, pacc + 1024, g, a.H, S, red, slot, nwaves, wave, tid, n);
-    if (a.src_kind == SRC_REC) {
-      if (a.Zbar) {
-        float* out = in_loop(a.Zbar) + rec_off;
+      ln_backward<NT, NX, FPT>(zc, pb, valid, gamv, al.G, pacc, pacc + 1024, g, al.H, S, red, slot, nwaves, wave, tid, n);
+    if (al.src_kind == SRC_REC) {
+      if (al.Zbar) {
+        float* out = in_loop(al.Zbar) + rec_off;
 #pragma unroll
         for (int i = 0; i < FPT; ++i)
 #pragma unroll
-          for (int s = 0; s < K; ++s) rec_st(out, s * a.Hp + a.G * i, voff, pb[i][s]);
+          for (int s = 0; s < K; ++s) rec_st(out, s * al.Hp + al.G * i, voff, pb[i][s]);
       }
     } else if (enc_grad) {
       // first Linear: dW[f][c] += sum_n zb_0 coord_c (+ zb_t1 for the time column, + zb_x1 for column 0); db[f] += sum_n zb_0
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
         for (int cc = 0; cc < 4; ++cc) gw[cc] = pb[i][0] * xin[cc];
         if constexpr (NT >= 1) {
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) gw[cc] += (cc == a.din - 1) ? pb[i][1] : 0.0f;
+          for (int cc = 0; cc < 4; ++cc) gw[cc] += (cc == al.din - 1) ? pb[i][1] : 0.0f;
         }
         if constexpr (NX >= 1) gw[0] += pb[i][1 + NT];
         float gb = pb[i][0];
@@ -652,8 +658,8 @@ __global__ __launch_bounds__(1024) void lm_ew_bwd(const EwArgs a) {
         gb = pt_sum(gb);
         if (n == 0) {  // this thread group is the only writer of its features' slots
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) pacc[(2 + cc) * 1024 + g + a.G * i] += gw[cc];
-          pacc[6 * 1024 + g + a.G * i] += gb;
+          for (int cc = 0; cc < 4; ++cc) pacc[(2 + cc) * 1024 + g + al.G * i] += gw[cc];
+          pacc[6 * 1024 + g + al.G * i] += gb;
         }
       }
     }
