@@ -184,6 +184,11 @@ def test_baseline_networks_full_depth_gradient(name, arch, pde_name, dim, kw, de
     ("resnet", "allen_cahn", dict(hidden_dim=512, num_layers=1, num_blocks=1, activation="tanh")),
     ("feedforward", "kdv", dict(hidden_dim=124, num_layers=3, activation="tanh", layer_norm=True)),  # YAML default shape
     ("siren", "kdv", dict(hidden_dims=[124, 124], omega_0=6.0)),
+    # LayerNorm widths between the tested 128 and 256: 6 / 10 / 13 waves per workgroup in the element-wise kernels and
+    # in the LDS-DMA prefetch of the LayerNorm adjoint (pieces = K * Hp / 16 per record)
+    ("resnet", "allen_cahn", dict(hidden_dim=96, num_layers=2, num_blocks=2, activation="tanh")),
+    ("resnet", "burgers", dict(hidden_dim=160, num_layers=2, num_blocks=2, activation="gelu")),
+    ("attention", "burgers", dict(hidden_dim=200, num_layers=2, num_heads=4, activation="gelu")),
 ])
 @pytest.mark.parametrize("engine", ["default", "lm"])
 def test_arbitrary_widths(arch, pde_name, kw, engine, dev):
