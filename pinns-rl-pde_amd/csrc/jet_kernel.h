@@ -88,6 +88,7 @@ struct KernelArgs {
   unsigned long long* stamps;               // diagnostic builds (-DPINN_STAMPS) only: [grid][4 waves][kNumStamps] cycles
   long long det_stride;                     // deterministic mode: the gradient / loss pointers above point into row 0 of a
                                             // [grid][det_stride] slab and workgroup b adds (plainly) into row b; 0 = atomics
+  int det_mask;                             // two-level flush (det_stride < 0): rows - 1, a power of two minus one
 };
 
 // Gradient / loss accumulation at the end of a workgroup (or per tile for layers beyond the persistent ones): float
@@ -95,7 +96,11 @@ struct KernelArgs {
 // (the pointers then point into row 0): nobody else touches that row, every address gets its adds in program order
 // (at most two per flush, which commute exactly from a zero start), and a fixed-order reduction sums the rows
 // afterwards (pinn_abi.hip).  One code path: the row offset is simply 0 when the mode is off.
-__device__ __forceinline__ long long det_row_offset(const KernelArgs& a) { return (long long)blockIdx.x * a.det_stride; }
+__device__ __forceinline__ long long det_row_offset(const KernelArgs& a) {
+  // det_stride > 0: one row per workgroup (deterministic mode); < 0: det_mask + 1 shared rows of -det_stride floats
+  // (two-level flush: fewer workgroups contend for an address); 0: the caller's tensors directly
+  return a.det_stride >= 0 ? (long long)blockIdx.x * a.det_stride : (long long)(blockIdx.x & a.det_mask) * -a.det_stride;
+}
 __device__ __forceinline__ void grad_add(float* p, float v, long long off) { atomicAdd(p + off, v); }
 
 // Every kernel of this family may use the whole 160 KB LDS of a CU as dynamic shared memory.  The attribute is set

@@ -147,6 +147,8 @@ static bool build_wide(const PinnNetDesc* d, const float* const* w, float* const
 // Every gradient / loss pointer of the NetDev is redirected into row 0 of a [grid][stride] slab in the workspace;
 // workgroup b adds into row b with plain (non-atomic) adds, and this kernel then sums the rows of every element in
 // workgroup order and adds the total to the caller's tensor: two launches on the same inputs give identical bits.
+constexpr int kFlushRows = 8;  // shared slab rows of the default (non-deterministic) two-level flush
+
 struct DetTable {
   int n;
   float* user[2 * PINN_MAX_LINEAR + 8];
@@ -300,7 +302,15 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
 #ifdef PINN_STAMPS
     a.stamps = g_stamps;
 #endif
-    const bool det = (net->flags & PINN_FLAG_DETERMINISTIC) != 0;
+    // Default mode of a reverse launch: TWO-LEVEL flush.  Workgroup b adds (atomically) into row b mod 8 of an 8-row
+    // slab and a small launch sums the rows into the caller's tensors: 32 instead of 256 workgroups contend for an
+    // address.  Measured on the headline launch (kernel + memset + row sum, events around the call): direct atomics
+    // 0.554 ms, 2 rows 0.553, 4 rows 0.549, 8 rows 0.543, 16 rows 0.545, 32 rows 0.550, 64 rows 0.567.
+    const int shared_rows = kFlushRows;
+    const bool det_flag = (net->flags & PINN_FLAG_DETERMINISTIC) != 0;
+    const bool two_level = !det_flag && bwd && grid > shared_rows;
+    const bool det = det_flag || two_level;
+    const int slab_rows = two_level ? shared_rows : grid;
     const size_t tape_floats = bwd ? (size_t)jet_tape_floats_per_wg(K, a.net.n_layers, 1) * grid : 0;
     size_t need = tape_floats * sizeof(float);
     DetTable dt;
@@ -309,7 +319,7 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
       NetDev probe = a.net;
       float* lprobe = a.loss_sum;
       det_redirect(probe, lprobe, nullptr, dt);  // sizing pass: the same stride pinn_workspace_bytes reports
-      need += (size_t)dt.stride * grid * sizeof(float);
+      need += (size_t)dt.stride * slab_rows * sizeof(float);
     }
     if (need > 0 && (!workspace || ws_bytes < need))
       return fail(PINN_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
@@ -324,14 +334,15 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
       slab = static_cast<float*>(workspace) + tape_floats;
       det_redirect(a.net, a.loss_sum, slab, dt);
       dt.stride = stride;  // rows are as wide as the sizing pass said, whatever subset of targets this call has
-      a.det_stride = stride;
-      const hipError_t em = hipMemsetAsync(slab, 0, (size_t)stride * grid * sizeof(float), static_cast<hipStream_t>(stream));
+      a.det_stride = two_level ? -(long long)stride : (long long)stride;
+      a.det_mask = slab_rows - 1;
+      const hipError_t em = hipMemsetAsync(slab, 0, (size_t)stride * slab_rows * sizeof(float), static_cast<hipStream_t>(stream));
       if (em != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)em, hipGetErrorString(em));
     }
     hipError_t e = dispatch_wide(nt, nx, a, bwd, grid, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)e, hipGetErrorString(e));
     if (det && dt.n > 0) {
-      hipLaunchKernelGGL(wide_det_reduce, dim3(32, dt.n), dim3(256), 0, static_cast<hipStream_t>(stream), dt, slab, grid);
+      hipLaunchKernelGGL(wide_det_reduce, dim3(32, dt.n), dim3(256), 0, static_cast<hipStream_t>(stream), dt, slab, slab_rows);
       e = hipGetLastError();
       if (e != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)e, hipGetErrorString(e));
     }
@@ -423,6 +434,11 @@ size_t pinn_workspace_bytes(const PinnNetDesc* net, int64_t N, int32_t time_orde
       float* lprobe = nullptr;
       det_redirect(n, lprobe, nullptr, dt);
       bytes += (size_t)dt.stride * grid * sizeof(float);
+    } else if (bwd && grid > (size_t)kFlushRows) {  // the two-level flush's shared rows
+      DetTable dt;
+      float* lprobe = nullptr;
+      det_redirect(n, lprobe, nullptr, dt);
+      bytes += (size_t)dt.stride * kFlushRows * sizeof(float);
     }
     return bytes;
   }
