@@ -324,6 +324,8 @@ def main():
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(),
                 "kernel": "pinn::jet_kernel_wide<tanh, NT=1, NX=2, reverse>", "kernel_ms": kern_ms,
+                "kernel_ms_covers": "the call's launches between events on the launch stream: 1.3 MB memset of the flush rows, "
+                                    "the fused kernel, the 8-row gradient sum",
                 "flops_per_point": flops_pt,
             },
             "residual_l2_theta0": math.sqrt(float(loss_sum) / n_global),
