@@ -40,15 +40,15 @@ def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
     (profiles/r02_bench.json, made by tools/profile_summary.py): FETCH_SIZE (x2: gfx950 counts 64 B per 128-B
     request) + WRITE_SIZE, both KiB.  None when no profile has been committed."""
-    for name in ("r02_bench.json", "r01_bench.json"):
+    for name in ("r03_bench.json", "r02_bench.json", "r01_bench.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 h = json.load(f).get("hbm_bytes_per_launch")
             if h:
-                return float(h["read_x2"] + h["write"])
+                return float(h["read_x2"] + h["write"]), "profiles/" + name
         except (OSError, ValueError, KeyError):
             continue
-    return None
+    return None, None
 
 
 def host_threads() -> int:
@@ -102,49 +102,80 @@ def gpu_points_per_s(E, prog, pd, x, t, buf, n_grad, steps=30):
 def training_parity(dev, O, pspec, aspec, steps=200, batch=5000, lr=1e-3, clip=1.0):
     """Second half of the metric: sqrt(mean r^2) on the fixed 49 729-point grid after a fixed schedule, on the GPU
     (PDETrainer's autograd-free step) and on the CPU (oracle.compute_loss_terms + torch Adam + clip_grad_norm_) from
-    the same theta_0 (seed 0) and the same batches (product sampler on the device, seed 2, copied to the host)."""
+    the same theta_0 (seed 0) and the same batches (product sampler on the device, seed 2, copied to the host).
+
+    Two controls put the 200-step theta distance into context: the SAME CPU schedule run with one thread
+    instead of all of them (different fp32 summation orders inside the reference's own kernels), and a GPU run with
+    deterministic reductions.  `theta_rel_l2_by_step` of each is the relative L2 distance to the all-threads CPU run."""
     from __graft_entry__ import _burgers
     from pinnrl_amd.config import TrainingConfig
     from pinnrl_amd.training import PDETrainer
 
-    cfg, model, pde = _burgers(dev, hidden=128, layers=4, mapping=32, scale=10.0, seed=0)
-    cfg.device = dev
-    cfg.training = TrainingConfig(learning_rate=lr, gradient_clipping=clip)
-    tr = PDETrainer(model, pde, {}, cfg, device=dev)
-    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    assert tr._manual_step_unsupported() is None
-    tr._build_flat_state()
-    torch.manual_seed(2)
-    batches, snaps = [], {}
-    for s in range(1, steps + 1):
-        x, t = pde.generate_collocation_points(batch, strategy="uniform")
-        batches.append((x.cpu(), t.cpu()))
-        tr.train_step(x, t)
-        if s in (1, 3, 10, 30, 100, steps):
-            snaps[s] = torch.cat([p.detach().flatten().cpu() for _, p in model.named_parameters()])
+    marks = (1, 3, 10, 30, 100, steps)
+
+    def gpu_run(deterministic, batches=None):
+        cfg, model, pde = _burgers(dev, hidden=128, layers=4, mapping=32, scale=10.0, seed=0)
+        cfg.device = dev
+        cfg.training = TrainingConfig(learning_rate=lr, gradient_clipping=clip)
+        if deterministic:
+            model.set_deterministic(True)
+        tr = PDETrainer(model, pde, {}, cfg, device=dev)
+        sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        assert tr._manual_step_unsupported() is None
+        tr._build_flat_state()
+        made, snaps = [], {}
+        torch.manual_seed(2)
+        for s in range(1, steps + 1):
+            if batches is None:
+                x, t = pde.generate_collocation_points(batch, strategy="uniform")
+                made.append((x.cpu(), t.cpu()))
+            else:
+                x, t = batches[s - 1][0].to(dev), batches[s - 1][1].to(dev)
+            tr.train_step(x, t)
+            if s in marks:
+                snaps[s] = torch.cat([p.detach().flatten().cpu() for _, p in model.named_parameters()])
+        return model, pde, sd0, (made if batches is None else batches), snaps
+
+    model, pde, sd0, batches, snaps = gpu_run(False)
     torch.manual_seed(3)
     xg, tg = pde.generate_collocation_points(50000, strategy="uniform")  # the fixed evaluation grid (49 729 points)
     with torch.no_grad():
         r_gpu = pde.compute_residual(model, xg, tg)
         u_gpu = model(torch.cat([xg, tg], 1))
     torch.cuda.synchronize()
-    # CPU reference path
-    torch.set_num_threads(host_threads())
-    params = {k: v.clone().requires_grad_(k != "model.fourier.B") for k, v in sd0.items()}
-    names = [k for k in params if params[k].requires_grad]
-    opt = torch.optim.Adam([params[k] for k in names], lr=lr)
+    _, _, _, _, snaps_det = gpu_run(True, batches)
+    torch.cuda.synchronize()
+
     bc = O.PdeSpec(name="burgers", parameters=pspec.parameters, boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}},
                    initial_condition={"type": "sine", "amplitude": -1.0, "frequency": 1.0})
-    drift, t0 = {}, time.perf_counter()
-    for s, (xb, tb) in enumerate(batches, start=1):
-        opt.zero_grad()
-        O.compute_loss_terms(bc, lambda z: O.network_forward(aspec, params, z), xb, tb)["total"].backward()
-        torch.nn.utils.clip_grad_norm_([params[k] for k in names], clip)
-        opt.step()
-        if s in snaps:
-            ref = torch.cat([params[k].detach().flatten() for k in names])
-            drift[s] = float((snaps[s] - ref).norm() / ref.norm())
-    cpu_s = time.perf_counter() - t0
+
+    def cpu_run(threads):
+        torch.set_num_threads(threads)
+        params = {k: v.clone().requires_grad_(k != "model.fourier.B") for k, v in sd0.items()}
+        names = [k for k in params if params[k].requires_grad]
+        opt = torch.optim.Adam([params[k] for k in names], lr=lr)
+        out, t0 = {}, time.perf_counter()
+        for s, (xb, tb) in enumerate(batches, start=1):
+            opt.zero_grad()
+            O.compute_loss_terms(bc, lambda z: O.network_forward(aspec, params, z), xb, tb)["total"].backward()
+            torch.nn.utils.clip_grad_norm_([params[k] for k in names], clip)
+            opt.step()
+            if s in marks:
+                out[s] = torch.cat([params[k].detach().flatten() for k in names])
+        return params, out, time.perf_counter() - t0
+
+    nthr = host_threads()
+    params, ref, cpu_s = cpu_run(nthr)
+    _, ref1, cpu1_s = cpu_run(1)
+    torch.set_num_threads(nthr)
+
+    def drift(a):
+        return {str(k): float((a[k] - ref[k]).norm() / ref[k].norm()) for k in sorted(ref)}
+
+    def within(d):
+        return max([int(k) for k, v in d.items() if v <= 1e-5], default=0)
+
+    d_gpu, d_det, d_cpu1 = drift(snaps), drift(snaps_det), drift(ref1)
     xc, tc = xg.cpu(), tg.cpu()
     sdT = {k: v.detach() for k, v in params.items()}
     r_cpu = O.compute_residual(pspec, lambda z: O.network_forward(aspec, sdT, z), xc, tc).detach()
@@ -158,8 +189,13 @@ def training_parity(dev, O, pspec, aspec, steps=200, batch=5000, lr=1e-3, clip=1
         "final_residual_l2_rel_diff": abs(l2_gpu - l2_cpu) / l2_cpu,
         "residual_field_rel_l2": float((r_gpu.cpu() - r_cpu).norm() / r_cpu.norm()),
         "u_rel_l2": float((u_gpu.cpu() - u_cpu).norm() / u_cpu.norm()),
-        "theta_rel_l2_by_step": {str(k): v for k, v in sorted(drift.items())},
-        "steps_within_1e-5": max([k for k, v in drift.items() if v <= 1e-5], default=0),
+        "theta_rel_l2_by_step": d_gpu, "steps_within_1e-5": within(d_gpu),
+        "gpu_deterministic": {"theta_rel_l2_by_step": d_det, "steps_within_1e-5": within(d_det),
+                              "note": "same batches, PINNModel.set_deterministic(True): fixed-order gradient reductions"},
+        "cpu_control": {"theta_rel_l2_by_step": d_cpu1, "steps_within_1e-5": within(d_cpu1), "threads": [nthr, 1],
+                        "cpu_seconds_1thread": cpu1_s,
+                        "note": "the reference CPU path against ITSELF: same schedule, same batches, 1 thread vs all threads "
+                                "(summation order inside torch's CPU kernels) - the reference's own reproducibility envelope"},
         "eval_grid_points": int(xg.shape[0]), "cpu_seconds": cpu_s,
     }
 
@@ -173,9 +209,14 @@ def secondary_configs(E):
     for tag in ("C1", "C3", "C4", "C5"):
         name, net, eq, n_req = B.CONFIGS[tag]()
         torch.manual_seed(1)
-        if tag == "C3":
-            x = torch.rand(n_req, 1, device=B.dev) * 2 - 1
-            t = torch.rand(n_req, 1, device=B.dev)
+        sampler = "uniform"
+        if tag == "C3":  # BASELINE C3: DQN adaptive sampling (pde_base.py:961-1073), exploit branch (spread over the domain)
+            from pinnrl_amd.rl import RLAgent
+
+            eq.rl_agent = RLAgent(state_dim=2, action_dim=1, hidden_dim=64, device=B.dev)
+            eq.rl_agent.epsilon = 0.0
+            x, t = eq.generate_collocation_points(n_req, strategy="adaptive")
+            sampler = "adaptive (DQN agent, epsilon 0)"
         else:
             x, t = eq.generate_collocation_points(n_req, strategy="uniform")
         N = x.shape[0]
@@ -195,10 +236,10 @@ def secondary_configs(E):
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / steps
         tf = 3 * K * prog.flops_per_point() * N / (ms * 1e-3) / 1e12
-        out[tag] = {"workload": name, "points": N, "streams": K, "ms_per_step": ms, "points_per_s": N / ms * 1e3,
+        out[tag] = {"workload": name, "points": N, "sampler": sampler, "streams": K, "ms_per_step": ms, "points_per_s": N / ms * 1e3,
                     "tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS,
                     "engine": "fused tile-major kernel (jet_kernel_wide)" if tag == "C1" else
-                              "layer-major engine (lm_gemm / lm_gemm_nt8 / lm_ew_*; per-kernel split: profiles/r02_" + tag + ".md)"}
+                              "layer-major engine (lm_fused / lm_gemm_nt8 / lm_gemm / lm_ew_*; per-kernel split: profiles/r03_" + tag + ".md)"}
         del net, eq, x, t, flat
         torch.cuda.empty_cache()
     return out
@@ -212,7 +253,8 @@ def main():
     ap.add_argument("--points", type=int, default=50000,
                     help="requested collocation points: per GPU (weak) or in total (strong); uniform -> floor(sqrt)^2")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--spinup", type=int, default=100, help="untimed launches before the warm-up steps (clock ramp)")
+    ap.add_argument("--spinup", type=int, default=0, help="extra untimed launches before the warm-up steps (experiments; "
+                    "the sustained-clock figure is reported separately as `sustained`)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the final-residual-L2 schedule")
@@ -270,9 +312,9 @@ def main():
         if world > 1:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
 
-    # device spin-up, before and in addition to the W warm-up steps: the first few dozen launches after an idle period
-    # run below the sustained clock (measured: 0.58 ms per launch in a 5 + 20 run against 0.556 after 100 launches);
-    # untimed, counted in config.spin_up_launches
+    # (--spinup N: extra untimed launches, off by default — the driver's --warmup means what it says.  The first few
+    # dozen launches after an idle period run below the sustained clock; that figure is measured AFTER the timed region
+    # and reported separately as `sustained`.)
     for _ in range(args.spinup):
         step()
     for _ in range(args.warmup):
@@ -292,11 +334,61 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    # sustained-clock figure, outside the timed region: 100 more launches, then 50 timed ones
+    sustained = None
+    if world == 1:
+        for _ in range(100):
+            step()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+        sus_ms = 1e3 * (time.perf_counter() - ts) / 50
+        sustained = {"after_untimed_launches": args.spinup + args.warmup + args.steps + 100, "steps": 50, "ms_per_step": sus_ms,
+                     "value": n_global / sus_ms * 1e3}
+
+    # north_star's ">= 6x strong scaling at 8 GPUs": beside the weak-scaling `value`, every N > 1 run also times ONE global
+    # 10^6-point batch split over the ranks by shard_bounds (+ the all-reduce) against the same batch on rank 0 alone
+    strong_fig = None
+    if world > 1:
+        torch.manual_seed(7)  # identical on every rank
+        xs, ts_ = pde.generate_collocation_points(1000000, strategy="uniform")
+        ns = xs.shape[0]
+        lo, hi = D.shard_bounds(ns, rank, world)
+
+        def timed(xa, ta, reduce, reps=10):
+            for _ in range(3):
+                buf.zero_()
+                E.residual_loss_grad(prog, pd, xa, ta, 1.0 / ns, flat, loss_sum=loss_sum)
+                if reduce:
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            t_0 = time.perf_counter()
+            for _ in range(reps):
+                buf.zero_()
+                E.residual_loss_grad(prog, pd, xa, ta, 1.0 / ns, flat, loss_sum=loss_sum)
+                if reduce:
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t_0) / reps
+
+        dist.barrier()
+        ms_n = torch.tensor([timed(xs[lo:hi].contiguous(), ts_[lo:hi].contiguous(), True)], dtype=torch.float64, device=dev)
+        dist.all_reduce(ms_n, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        ms_1 = timed(xs, ts_, False) if rank == 0 else 0.0  # the other ranks idle meanwhile
+        dist.barrier()
+        strong_fig = {"points": int(ns), "ms_1": ms_1, "ms_N": float(ms_n), "speedup": (ms_1 / float(ms_n)) if rank == 0 else None,
+                      "n_gpus": world, "note": "one global batch split by shard_bounds + 1 all-reduce of [grad || loss] per step, "
+                                               "max over ranks, vs the same batch on rank 0 alone"}
+        del xs, ts_
 
     if rank == 0:
         K = 4
         flops_pt = 3 * K * prog.flops_per_point()  # forward jets + delta-propagation + weight-gradient GEMMs
         achieved = flops_pt * N / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic()
         out = {
             "metric": "collocation-points/sec (residual+grad) + final residual L2, Burgers 1D",
             "value": n_global * args.steps / elapsed,
@@ -318,16 +410,20 @@ def main():
                 "points_per_gpu": N, "global_points": n_global, "streams": K,
                 "collective": "none" if world == 1 else f"1 all-reduce/step of [grad || loss] ({n_grad + 4} floats)",
                 "sampler": "pde.generate_collocation_points(strategy='uniform') on the device",
-                "spin_up_launches": args.spinup,
+                "untimed_launches": args.spinup + args.warmup,
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(),
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "traffic_source": (traffic_src + ": rocprofv3 FETCH_SIZE (x2) + WRITE_SIZE passes of this command, committed; not "
+                                   "measured inside this run") if traffic_src else None,
                 "kernel": "pinn::jet_kernel_wide<tanh, NT=1, NX=2, reverse>", "kernel_ms": kern_ms,
                 "kernel_ms_covers": "the call's launches between events on the launch stream: 1.3 MB memset of the flush rows, "
                                     "the fused kernel, the 8-row gradient sum",
                 "flops_per_point": flops_pt,
             },
+            "sustained": sustained,
+            "strong": strong_fig,
             "residual_l2_theta0": math.sqrt(float(loss_sum) / n_global),
             "build_info": _lib.build_info() or "all kernel units in their preferred form",
         }

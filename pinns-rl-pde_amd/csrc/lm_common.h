@@ -47,6 +47,7 @@ struct PackItem {
   int rows_p;
   int transpose;     // 0: packed[r][c] = src[r][c];  1: packed[c][r] = src[r][c] (Fourier B (din, M) -> [M][4]);
                      // 2 / 3: MFMA A-fragment order of src / of src^T (see frag_index): what lm_gemm streams
+                     // 4 / 5: the same in the 16 x 16 x 4 order of the fused kernels (frag16_index)
 };
 
 struct PackTable {
@@ -61,6 +62,14 @@ struct PackTable {
 __host__ __device__ inline long long frag_index(int r, int c, int nch) {
   const int rt = r >> 5, ln = r & 31, ch = c >> 5, g = (c & 31) >> 3, lh = (c & 7) >> 2, i = c & 3;
   return ((((long long)(rt * nch + ch) * 4 + g) * 64 + lh * 32 + ln) * 4 + i);
+}
+
+// A-operand order of v_mfma_f32_16x16x4_f32 for the fused kernels (lm_fused.h): lane l = 16 kk + lr of the wave that owns
+// row tile rt needs, for 16-row block mb and k-step j, A[32 rt + 16 mb + lr][4 j + kk]; the four k-steps 4 j4 .. 4 j4 + 3
+// of a lane are one 16-byte word, the 64 lanes of a (block, j4) pair 1 KB of consecutive memory.  nj4 = columns / 16.
+__host__ __device__ inline long long frag16_index(int r, int c, int nj4) {
+  const int rt = r >> 5, mb = (r >> 4) & 1, lr = r & 15, j = c >> 2, kk = c & 3;
+  return ((((long long)(rt * 2 + mb) * nj4 + (j >> 2)) * 64 + kk * 16 + lr) * 4 + (j & 3));
 }
 
 }  // namespace lm

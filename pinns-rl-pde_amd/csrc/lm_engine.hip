@@ -10,6 +10,7 @@
 #include <set>
 #include <vector>
 
+#include "lm_fused.h"
 #include "lm_gemm.h"
 
 namespace pinn {
@@ -25,12 +26,13 @@ __global__ void lm_pack_kernel(const PackTable tab, float* packed) {
     const int r = i / it.cols_p, c = i - r * it.cols_p;
     float v = 0.0f;
     long long dst = i;
-    if (it.transpose == 1 || it.transpose == 3) {
+    if (it.transpose == 1 || it.transpose == 3 || it.transpose == 5) {
       if (c < it.rows && r < it.cols) v = it.src[c * it.cols + r];
     } else {
       if (r < it.rows && c < it.cols) v = it.src[r * it.cols + c];
     }
-    if (it.transpose >= 2) dst = frag_index(r, c, it.cols_p >> 5);
+    if (it.transpose >= 4) dst = frag16_index(r, c, it.cols_p >> 4);
+    else if (it.transpose >= 2) dst = frag_index(r, c, it.cols_p >> 5);
     packed[it.off + dst] = v;
   }
 }
@@ -212,6 +214,11 @@ struct Program {
   struct Derived {
     int wp, bp, wv, bv, H;
   } derived[kMaxNodes / 3 + 1];
+  // fused GEMM + prologue launches (lm_fused.h), planned per call by plan_fusion()
+  struct Fuse {
+    bool on;
+    int nch, rt, gy;
+  } fuse_fwd[kMaxNodes], fuse_bwd[kMaxNodes];
 };
 
 void use_tensor(Program& P, int idx, int rows, int cols, bool enc4 = false, bool transpose = false) {
@@ -425,6 +432,88 @@ int build_program(const PinnNetDesc* d, Program& P, char* err, size_t en) {
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// fusion plan: which GEMM nodes run the consumer's prologue (forward) / their own prologue's adjoint (reverse) in
+// their epilogue (lm_fused.h).  PINN_LM_FUSED=0 keeps every node on the unfused kernels (experiments, second
+// implementation for the parity tests), read once.
+// ----------------------------------------------------------------------------------------------------------------
+bool fused_off() {
+  static const bool v = [] {
+    const char* e = getenv("PINN_LM_FUSED");
+    return e && atoi(e) == 0;
+  }();
+  return v;
+}
+
+bool fused_set_built(int nt, int nx) { return !(nt == 2); }  // time order 2 (wave, pendulum) stays unfused: see the Makefile
+
+// Which node kinds take the fused kernels.  Measured on MI355X (tools/micro/fused_bench.hip, tools/bench_configs.py): without
+// LayerNorm the fused launch beats GEMM + element-wise launch in both directions (C4 30.8 -> 25.5 ms); with LayerNorm the
+// forward launch wins where the consumer has no skip record, and the reverse launch — whose epilogue (two block
+// reductions, ~1 200 VALU instructions per wave and unit) runs with all eight waves in the same phase and nothing
+// overlapping it — only where the weight slice leaves the epilogue its registers (depth 128).  PINN_LM_FUSED_LN=<bits>
+// overrides: 1 forward, 2 forward with a skip record, 4 reverse at depth 128, 8 reverse at depth 256.
+int fused_ln_mask() {
+  static const int v = [] {
+    const char* e = getenv("PINN_LM_FUSED_LN");
+    return e ? atoi(e) : (1 | 4);
+  }();
+  return v;
+}
+
+bool fuse_shape(int rows, int depth, bool ln, Program::Fuse& f) {
+  const int rp = round32(rows), dp = round32(depth);
+  f.on = false;
+  if (dp != 128 && dp != 256) return false;
+  if (rp == 128 && dp == 128) {
+    f = {true, 4, 4, 1};
+    return true;
+  }
+  if (rp % 256 == 0 && (!ln || rp == 256)) {
+    f = {true, dp / 32, 8, rp / 256};
+    return true;
+  }
+  return false;
+}
+
+const Prologue& consumer_of(const Program& P, int m) { return m + 1 < P.n_nodes ? P.node[m + 1].pro : P.head; }
+
+void plan_fusion(Program& P, int nt, int nx) {
+  for (int m = 0; m < P.n_nodes; ++m) {
+    P.fuse_fwd[m].on = P.fuse_bwd[m].on = false;
+    if (fused_off() || !fused_set_built(nt, nx)) continue;
+    const Node& nd = P.node[m];
+    const Prologue& cp = consumer_of(P, m);
+    const int lnm = fused_ln_mask();
+    if (cp.src_kind == SRC_REC && cp.src_node == m && !cp.identity() && cp.H == nd.Hout && !(nd.add_node >= 0 && cp.skip_node >= 0) &&
+        (cp.ln_g < 0 || (lnm & (cp.skip_node >= 0 ? 2 : 1))))
+      fuse_shape(nd.Hout, nd.Hin, cp.ln_g >= 0, P.fuse_fwd[m]);
+    const Prologue& pro = nd.pro;
+    if (pro.src_kind == SRC_REC && !pro.identity() && (pro.ln_g < 0 || (lnm & (round32(nd.Hout) <= 128 ? 4 : 8))))
+      fuse_shape(nd.Hin, nd.Hout, pro.ln_g >= 0, P.fuse_bwd[m]);
+  }
+}
+
+#define PINN_LM_FDECL(nt, nx, act) \
+  hipError_t launch_lm_fused_##nt##_##nx##_##act(const FusedArgs&, bool bwd, bool ln, int nch, int rt, int gx, int gy, hipStream_t);
+#define PINN_LM_FDECL5(nt, nx) PINN_LM_FDECL(nt, nx, 0) PINN_LM_FDECL(nt, nx, 1) PINN_LM_FDECL(nt, nx, 2) PINN_LM_FDECL(nt, nx, 3) PINN_LM_FDECL(nt, nx, 4)
+}  // namespace
+PINN_LM_FDECL5(0, 0) PINN_LM_FDECL5(1, 0) PINN_LM_FDECL5(1, 1) PINN_LM_FDECL5(1, 2) PINN_LM_FDECL5(1, 3) PINN_LM_FDECL5(1, 4)
+#undef PINN_LM_FDECL5
+#undef PINN_LM_FDECL
+namespace {
+
+hipError_t launch_fused(int nt, int nx, int act, const FusedArgs& a, bool bwd, bool ln, const Program::Fuse& f, int gx, hipStream_t st) {
+  const int fam = (act == PINN_ACT_TANH || act == PINN_ACT_SIN || act == PINN_ACT_GELU || act == PINN_ACT_SIGMOID) ? act : PINN_ACT_RELU;
+#define PINN_LM_FCASE(NT_, NX_, A_) \
+  if (nt == NT_ && nx == NX_ && fam == A_) return launch_lm_fused_##NT_##_##NX_##_##A_(a, bwd, ln, f.nch, f.rt, gx, f.gy, st);
+#define PINN_LM_FCASE5(NT_, NX_) PINN_LM_FCASE(NT_, NX_, 0) PINN_LM_FCASE(NT_, NX_, 1) PINN_LM_FCASE(NT_, NX_, 2) PINN_LM_FCASE(NT_, NX_, 3) PINN_LM_FCASE(NT_, NX_, 4)
+  PINN_LM_FCASE5(0, 0) PINN_LM_FCASE5(1, 0) PINN_LM_FCASE5(1, 1) PINN_LM_FCASE5(1, 2) PINN_LM_FCASE5(1, 3) PINN_LM_FCASE5(1, 4)
+#undef PINN_LM_FCASE5
+#undef PINN_LM_FCASE
+  return hipErrorInvalidValue;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // workspace layout
 // ----------------------------------------------------------------------------------------------------------------
 struct Layout {
@@ -479,7 +568,7 @@ void make_layout(const Program& P, long long N, int K, bool bwd, bool determinis
       it.off = (unsigned)off;
       it.rows = P.node[m].Hout;
       it.cols = P.node[m].Hin;
-      it.transpose = 2 + tr;
+      it.transpose = ((tr ? P.fuse_bwd[m].on : P.fuse_fwd[m].on) ? 4 : 2) + tr;  // fused kernels: 16 x 16 x 4 operand order
       it.rows_p = round32(tr ? P.node[m].Hin : P.node[m].Hout);
       it.cols_p = round32(tr ? P.node[m].Hout : P.node[m].Hin);
       off += (size_t)it.rows_p * it.cols_p;
@@ -699,6 +788,7 @@ size_t lm_workspace_bytes(const PinnNetDesc* d, long long N, int nt, int nx, boo
   Program P;
   char err[64];
   if (build_program(d, P, err, sizeof(err)) != PINN_OK) return 0;
+  plan_fusion(P, nt, nx);
   Layout L;
   make_layout(P, N, 1 + nt + nx, bwd, deterministic, L);
   return (L.total * sizeof(float) + 255) & ~(size_t)255;
@@ -711,6 +801,7 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
   if (c.num_tensors != P.n_tensors)
     return failf(err, en, PINN_ERR_BAD_DESC, "weight table has %d entries, this architecture's state_dict has %d", c.num_tensors, P.n_tensors);
   const int K = 1 + c.nt + c.nx;
+  plan_fusion(P, c.nt, c.nx);
   static thread_local Layout L;  // 10 KB of offsets: keep it off the stack
   make_layout(P, c.N, K, c.bwd, c.deterministic, L);
   const size_t need = (L.total * sizeof(float) + 255) & ~(size_t)255;
@@ -827,14 +918,47 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
     const long long p_base = t0 * kT;
     const int ncb = (int)(ct * K);
     // ---------------- forward ----------------
+    bool v_ready[kMaxNodes + 1];  // V record already written by the producing node's fused epilogue
+    for (int m = 0; m <= kMaxNodes; ++m) v_ready[m] = false;
+    auto fused_grid = [&](const Program::Fuse& f) {
+      long long g = cus / f.gy;
+      if (g < 1) g = 1;
+      return (int)(g < ct ? g : ct);
+    };
     for (int m = 0; m < P.n_nodes; ++m) {
       const Node& nd = P.node[m];
-      if (!nd.pro.identity()) {
+      if (!nd.pro.identity() && !v_ready[m]) {
         EwArgs a;
         const int fpt = fill_ew(a, nd.pro, ct, p_base, m);
         a.V = ws + L.V[m];
         if (nd.pro.src_kind == SRC_COORDS_FOURIER) LM_CHECK(launch_ew(c.nt, c.nx, a, false, -2, fpt, ew_grid(ct, a.G), st));
         else LM_CHECK(launch_ew(c.nt, c.nx, a, false, nd.pro.act, fpt, ew_grid(ct, a.G), st));
+      }
+      if (P.fuse_fwd[m].on) {  // Y[m] = W V + b (+ add) and the consumer's prologue in one launch
+        const bool to_head = m + 1 >= P.n_nodes;
+        const Prologue& cp = consumer_of(P, m);
+        const int self = to_head ? kMaxNodes : m + 1;
+        FusedArgs f;
+        memset(&f, 0, sizeof(f));
+        f.W = params + L.tab.item[P.n_tensors + 2 * m].off;
+        f.bias = pp(nd.b);
+        f.X = ws + L.V[m];
+        f.rows_p = round32(nd.Hout);
+        f.rows = nd.Hout;
+        f.ntiles = ct;
+        f.add0 = nd.add_node >= 0 ? ws + L.V[nd.add_node] : nullptr;
+        f.Y = ws + L.Y[m];
+        f.ln_g = pp(cp.ln_g);
+        f.ln_b = pp(cp.ln_b);
+        f.eps = P.ln_eps;
+        f.skip = cp.skip_node >= 0 ? ws + L.V[cp.skip_node] : nullptr;
+        f.has_act = cp.act >= 0;
+        f.act_param = cp.act_param;
+        f.V = ws + (to_head ? L.Vh : L.V[m + 1]);
+        f.stats = (c.bwd && L.Stats[self]) ? ws + L.Stats[self] : nullptr;
+        LM_CHECK(launch_fused(c.nt, c.nx, cp.act, f, false, cp.ln_g >= 0, P.fuse_fwd[m], fused_grid(P.fuse_fwd[m]), st));
+        v_ready[self] = true;
+        continue;
       }
       GemmArgs g;
       memset(&g, 0, sizeof(g));
@@ -853,7 +977,8 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       EwArgs a;
       const int fpt = fill_ew(a, P.head, ct, p_base, kMaxNodes);
       a.V = ws + L.Vh;
-      if (P.head.src_kind == SRC_COORDS_FOURIER) LM_CHECK(launch_ew(c.nt, c.nx, a, false, -2, fpt, ew_grid(ct, a.G), st));
+      if (v_ready[kMaxNodes]) {
+      } else if (P.head.src_kind == SRC_COORDS_FOURIER) LM_CHECK(launch_ew(c.nt, c.nx, a, false, -2, fpt, ew_grid(ct, a.G), st));
       else LM_CHECK(launch_ew(c.nt, c.nx, a, false, P.head.act, fpt, ew_grid(ct, a.G), st));
       HeadArgs h;
       memset(&h, 0, sizeof(h));
@@ -1002,6 +1127,46 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       const bool upstream = pro.src_kind == SRC_REC || pro.src_kind == SRC_COORDS_LINEAR || pro.ln_g >= 0 || pro.skip_node >= 0;
       if (!upstream) continue;
       if (pro.src_kind == SRC_COORDS_LINEAR && !gp(pro.enc_w) && !gp(pro.enc_b) && pro.ln_g < 0 && pro.skip_node < 0) continue;
+      if (P.fuse_bwd[m].on) {  // Vbar = W^T Zbar (+ extras) and the prologue's adjoint in one launch
+        FusedArgs f;
+        memset(&f, 0, sizeof(f));
+        f.W = params + L.tab.item[P.n_tensors + 2 * m + 1].off;
+        f.X = zbar;
+        f.rows_p = round32(nd.Hin);
+        f.rows = nd.Hin;
+        f.ntiles = ct;
+        f.add0 = extra[m][0];
+        f.add1 = extra[m][1];
+        f.ln_g = pp(pro.ln_g);
+        f.ln_b = pp(pro.ln_b);
+        f.eps = P.ln_eps;
+        f.skip = pro.skip_node >= 0 ? ws + L.V[pro.skip_node] : nullptr;
+        f.has_act = pro.act >= 0;
+        f.act_param = pro.act_param;
+        f.stats = L.Stats[m] ? ws + L.Stats[m] : nullptr;
+        f.Zsrc = ws + L.Y[pro.src_node];
+        f.Zbar = ws + L.Zbar[pro.src_node];
+        if (pro.skip_node >= 0) {
+          f.Pbar = ws + L.Pbar[m];
+          add_extra(pro.skip_node, f.Pbar);
+        }
+        f.d_ln_g = gp(pro.ln_g);
+        f.d_ln_b = gp(pro.ln_b);
+        if (c.deterministic && pro.ln_g >= 0) f.det_partial = ws + L.det;
+        const int fgrid = fused_grid(P.fuse_bwd[m]);
+        LM_CHECK(launch_fused(c.nt, c.nx, pro.act, f, true, pro.ln_g >= 0, P.fuse_bwd[m], fgrid, st));
+        if (f.det_partial) {
+          SlotReduce r;
+          memset(&r, 0, sizeof(r));
+          r.row = 7 * 1024;
+          r.n = 2;
+          r.dst[0] = f.d_ln_g; r.slot[0] = 0; r.mul[0] = 1; r.len[0] = nd.Hin;
+          r.dst[1] = f.d_ln_b; r.slot[1] = 1024; r.mul[1] = 1; r.len[1] = nd.Hin;
+          hipLaunchKernelGGL(lm_reduce_slots, dim3(4), dim3(256), 0, st, ws + L.det, fgrid, r);
+          LM_CHECK(hipGetLastError());
+        }
+        continue;
+      }
       GemmArgs g;
       memset(&g, 0, sizeof(g));
       g.W = params + L.tab.item[P.n_tensors + 2 * m + 1].off;  // W^T in fragment order (Hin_p x Hout_p)

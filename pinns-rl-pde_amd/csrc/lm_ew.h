@@ -73,6 +73,9 @@ __device__ __forceinline__ float rec_ld(const float* tile_base, int row, unsigne
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(tile_base + (long long)row * kT) + voff);
 }
 __device__ __forceinline__ void rec_st(float* tile_base, int row, unsigned voff, float v) {
+#ifdef PINN_FEXP_NOSTORE
+  if (v != 12345.678f) return;  // timing experiment (tools/micro/fused_bench.hip): the store never happens, its operand stays live
+#endif
   *reinterpret_cast<float*>(reinterpret_cast<char*>(tile_base + (long long)row * kT) + voff) = v;
 }
 // A kernel-argument pointer the optimizer may not reason about across loop iterations.  The element-wise kernels carry

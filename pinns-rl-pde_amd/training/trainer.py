@@ -60,7 +60,7 @@ class _EmaLossWeights:
 class PDETrainer:
     def __init__(self, model: nn.Module, pde, optimizer_config: Optional[Dict], config, device: Optional[torch.device] = None,
                  rl_agent=None, viz_frequency=10, validation_frequency=10, early_stopping_config=None,
-                 process_group=None, log_every_step: bool = False):
+                 process_group=None, log_every_step: bool = False, fast_step: Optional[bool] = None):
         self.device = device or (config.device if hasattr(config, "device") else torch.device("cpu"))
         self.model = model.to(self.device)
         self.pde = pde
@@ -69,6 +69,9 @@ class PDETrainer:
         self.logger = logging.getLogger(__name__)
         self.process_group = process_group
         self.log_every_step = log_every_step
+        # fast_step: None = `train()` takes the autograd-free launch list whenever it covers the configuration
+        # (`_manual_step_unsupported()` is None) and the device is a GPU; False = always the autograd step; True = require it
+        self.fast_step = fast_step
         if process_group is not None:
             # replicas must start from ONE theta_0 and apply identical updates: broadcast rank 0's parameters,
             # and refuse the modes whose per-rank quantities this path does not reduce
@@ -331,6 +334,7 @@ class PDETrainer:
                     steps = float(st["step"])
                 p.data = view
         g = self.optimizer.param_groups[0]
+        self.optimizer._opt_called = True  # the flat Adam kernel steps from now on; schedulers only read / write param_groups
         pde = self.pde
         inp_b, xb, tb, inp_i, xi, ti = pde._boundary_and_initial_points()
         x_all = torch.cat([xb, xi], 0).contiguous()
@@ -405,8 +409,13 @@ class PDETrainer:
                           beta2=F["betas"][1], eps=F["eps"], weight_decay=F["wd"],
                           max_norm=float(self.config.training.gradient_clipping))
 
-    def _manual_losses(self):
+    def _manual_losses(self, static: bool = False):
+        """{residual, boundary, initial, total} of the last manual step.  `static=True` hands out views of the persistent
+        summary buffer (what a captured graph refreshes in place); otherwise independent copies, so that a caller may
+        keep one per step (`train()` averages them per epoch)."""
         s = self._flat["summary"]
+        if not static:
+            s = s.clone()
         return {"residual": s[0], "boundary": s[1], "initial": s[2], "total": s[3]}
 
     def make_graphed_step(self, batch_size: int, warmup: int = 2):
@@ -441,7 +450,7 @@ class PDETrainer:
         with torch.cuda.graph(graph):
             step()
         self._step_graph = graph  # keeps the captured allocations alive
-        return graph.replay, self._manual_losses()
+        return graph.replay, self._manual_losses(static=True)
 
     def set_learning_rate(self, lr: float) -> None:
         """Propagate a scheduler's learning rate to the device scalar the captured / manual step reads."""
@@ -453,6 +462,12 @@ class PDETrainer:
         self.model.train()
         if self._is_lbfgs and batch_size != num_points:
             batch_size = num_points  # L-BFGS needs full-batch closures (trainer.py:455-461)
+        if getattr(self, "_flat", None) is None and self.fast_step is not False:
+            why = self._manual_step_unsupported()
+            if why is None and torch.device(self.device).type == "cuda":
+                self._build_flat_state()  # from here on `train_step` is the fixed launch list (no autograd)
+            elif self.fast_step:
+                raise NotImplementedError(f"fast_step=True, but the autograd-free step does not cover this configuration ({why})")
         trainable = dict(getattr(self.pde, "_trainable_params", {}))
         for name in trainable:
             self.history.setdefault(f"param_{name}", [])
@@ -464,7 +479,7 @@ class PDETrainer:
             for _ in range(num_points // batch_size):
                 x, t = self._sample(batch_size)
                 losses = self.train_step(x, t)
-                step_losses.append(losses["total"].detach())
+                step_losses.append(losses["total"].detach().clone())  # the manual step's losses may alias one buffer
                 if self.log_every_step:
                     self.points_history.append(torch.cat([x, t], dim=1).cpu().numpy())
             avg = float(torch.stack(step_losses).mean().item())  # ZeroDivisionError upstream when there are no steps

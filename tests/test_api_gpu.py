@@ -105,7 +105,10 @@ def test_layernorm_architectures_through_the_api(tag, dev):
         loss = pde._residual_loss(model, x, t)
     loss.backward()
     got = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten().cpu() for _, p in model.named_parameters()])
-    # attention: exact parity; resnet: within torch's fused-LayerNorm error of the reference
+    # LayerNorm networks are held to the EXACT derivative (composite-LayerNorm checker), not to torch's
+    # fused-layer_norm third derivative; the reference's own gradient stays a bounded witness of that difference
+    exact = a["grad64_exact"] if "grad64_exact" in a else a["grad64"]
+    assert rel_l2(got, exact) <= TOL, f"{rel_l2(got, exact):.3e}"
     assert rel_l2(got, a["grad64"]) <= (TOL if spec.architecture == "attention" else 5e-4)
 
 
@@ -195,6 +198,41 @@ def test_trainer_loop_runs_and_loss_decreases(dev):
     assert len(hist["train_loss"]) == 6 and len(hist["val_loss"]) == 3
     assert hist["train_loss"][-1] < hist["train_loss"][0]
     assert all(math.isfinite(v) for v in hist["train_loss"])
+
+
+def test_train_takes_the_manual_step_and_reports_the_epoch_mean(dev):
+    """`PDETrainer.train()` switches to the autograd-free launch list by itself when it covers the configuration, and
+    `history['train_loss']` is the mean of the epoch's per-step totals (the manual step's losses used to be
+    views of one buffer, so the 'mean' was the last step's value), equal to the autograd path's history."""
+    from __graft_entry__ import _burgers
+    from pinnrl_amd.config import TrainingConfig
+    from pinnrl_amd.training import PDETrainer
+
+    hists, per_step = {}, {}
+    for fast in (None, False):
+        cfg, model, pde = _burgers(dev)
+        cfg.device = dev
+        cfg.training = TrainingConfig(num_epochs=2, learning_rate=1e-3, gradient_clipping=1.0)
+        tr = PDETrainer(model, pde, {}, cfg, device=dev, validation_frequency=5, fast_step=fast)
+        seen = []
+        inner = tr.train_step
+
+        def spy(x, t, inner=inner, seen=seen):
+            out = inner(x, t)
+            seen.append(float(out["total"]))
+            return out
+
+        tr.train_step = spy
+        torch.manual_seed(0)
+        hists[fast] = tr.train(num_epochs=2, batch_size=1000, num_points=4000)
+        per_step[fast] = seen
+        assert (getattr(tr, "_flat", None) is not None) == (fast is None)
+    steps = per_step[None]
+    assert len(steps) == 8 and max(steps[:4]) - min(steps[:4]) > 0  # four distinct steps per epoch
+    for e in range(2):
+        mean = sum(steps[4 * e : 4 * e + 4]) / 4
+        assert abs(hists[None]["train_loss"][e] - mean) <= 1e-6 * abs(mean)
+        assert abs(hists[None]["train_loss"][e] - hists[False]["train_loss"][e]) <= 1e-4 * abs(mean)
 
 
 def test_graph_captured_step_equals_the_eager_step(dev):
