@@ -29,6 +29,7 @@ from .reference_path import (  # noqa: F401
     init_state_dict,
     make_agent,
     network_forward,
+    rar_probabilities,
     residual_loss_and_grad,
     sample_adaptive,
     sample_stratified,

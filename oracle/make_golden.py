@@ -275,6 +275,73 @@ def check_loss_terms():
         print(f"compute_loss restatement == reference for {name}: " + ", ".join(f"{k}={float(want[k].detach()):.6g}" for k in ("residual", "boundary", "initial", "total")))
 
 
+def check_data_modes(manifest: dict):
+    """Data-driven modes (pde_base.py:281-291, 1187-1233; upstream tests/unit_tests/test_train_data_modes.py): the oracle's
+    data term, mode gating and coefficient gradient against the reference, then a fixture of the reference's numbers."""
+    from pinnrl.config import AdaptiveWeightsConfig, EarlyStoppingConfig, LearningRateSchedulerConfig, TrainingConfig
+
+    def training(mode):
+        return TrainingConfig(num_epochs=1, batch_size=8, num_collocation_points=8, num_boundary_points=4, num_initial_points=4,
+                              learning_rate=1e-3, weight_decay=0.0, gradient_clipping=1.0,
+                              early_stopping=EarlyStoppingConfig(enabled=False, patience=999, min_delta=1e-7),
+                              learning_rate_scheduler=LearningRateSchedulerConfig(type="cosine", warmup_epochs=0, min_lr=1e-6, factor=0.5, patience=3),
+                              adaptive_weights=AdaptiveWeightsConfig(enabled=False),
+                              loss_weights={"residual": 1.0, "boundary": 10.0, "initial": 10.0, "data": 2.5}, mode=mode)
+
+    spec = O.ArchSpec("fourier", hidden_dim=32, num_layers=3, mapping_size=16, scale=4.0)
+    nu_true, nu_guess = 0.01 / math.pi, 0.05
+    torch.manual_seed(41)
+    model = make_ref_model(spec)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(42)
+    x = torch.rand(97, 1, generator=gen) * 2 - 1
+    t = torch.rand(97, 1, generator=gen)
+    obs = {"x": torch.rand(53, 1, generator=gen) * 2 - 1, "t": torch.rand(53, 1, generator=gen)}
+    obs["u"] = -torch.sin(math.pi * obs["x"]) * torch.exp(-obs["t"]) + 0.01 * torch.randn(53, 1, generator=gen)
+    arrays = {"x": x.numpy(), "t": t.numpy(), "obs_x": obs["x"].numpy(), "obs_t": obs["t"].numpy(), "obs_u": obs["u"].numpy(),
+              "nu_guess": np.float32(nu_guess)}
+    for k, v in sd.items():
+        arrays["sd/" + k] = v.numpy()
+    names = [k for k, _ in model.named_parameters()]
+    for mode in ("forward", "inverse", "data_only", "data_augmented"):
+        inverse = mode == "inverse"
+        cfg = PDEConfig(name="burgers", domain=[(-1.0, 1.0)], time_domain=(0.0, 1.0), parameters={"nu": nu_true},
+                        boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}},
+                        initial_condition={"type": "sine", "amplitude": -1.0, "frequency": 1.0}, exact_solution={}, dimension=1,
+                        device=CPU, training=training(mode), trainable_parameters=["nu"] if inverse else [],
+                        parameter_initial_guesses={"nu": nu_guess} if inverse else {},
+                        observation_data={k: v.clone() for k, v in obs.items()})
+        ref = BurgersEquation(config=cfg)
+        model.zero_grad()
+        want = ref.compute_loss(model, x.clone(), t.clone())
+        plist = [p for _, p in model.named_parameters()] + (list(ref.trainable_parameters_iter()) if inverse else [])
+        gw = torch.autograd.grad(want["total"], plist, allow_unused=True)
+        # oracle
+        params = {k: v.clone().requires_grad_(k != "model.fourier.B") for k, v in sd.items()}
+        nu = torch.tensor(nu_guess if inverse else nu_true, requires_grad=inverse)
+        pde = O.PdeSpec(name="burgers", parameters={"nu": nu if inverse else nu_true},
+                        boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}},
+                        initial_condition={"type": "sine", "amplitude": -1.0, "frequency": 1.0},
+                        loss_weights={"residual": 1.0, "boundary": 10.0, "initial": 10.0, "data": 2.5})
+        got = O.compute_loss_terms(pde, lambda z: O.network_forward(spec, params, z), x.clone(), t.clone(), observations=obs, mode=mode)
+        go = torch.autograd.grad(got["total"], [params[k] for k in names] + ([nu] if inverse else []), allow_unused=True)
+        for k in ("residual", "boundary", "initial", "data", "total"):
+            a, b = float(got[k].detach()), float(want[k].detach())
+            assert abs(a - b) <= 1e-6 * abs(b) + 1e-12, f"data modes[{mode}][{k}]: oracle {a} vs reference {b}"
+            arrays[f"{mode}/{k}"] = np.float32(b)
+        flat = lambda gs, ps: torch.cat([(g if g is not None else torch.zeros_like(p)).flatten() for g, p in zip(gs, ps)])  # noqa: E731
+        gw_t, go_t = flat(gw[: len(names)], plist[: len(names)]), flat(go[: len(names)], [params[k] for k in names])
+        assert rel_l2(go_t, gw_t) <= 1e-6, f"data modes[{mode}]: gradient {rel_l2(go_t, gw_t):.2e}"
+        arrays[f"{mode}/grad"] = gw_t.numpy()
+        if inverse:
+            assert abs(float(go[-1]) - float(gw[-1])) <= 1e-6 * abs(float(gw[-1])), "d total / d nu"
+            arrays["inverse/dnu"] = np.float32(float(gw[-1]))
+        print(f"data mode {mode}: oracle == reference (total {float(want['total'].detach()):.6g}, data {float(want['data'].detach()):.6g})")
+    np.savez(os.path.join(OUT, "data_modes.npz"), **arrays)
+    manifest["_data_modes"] = {"modes": ["forward", "inverse", "data_only", "data_augmented"], "pde": "burgers", "arch": "fourier 3x32",
+                              "points": 97, "observations": 53, "loss_weights": {"residual": 1.0, "boundary": 10.0, "initial": 10.0, "data": 2.5}}
+
+
 def quirk_witnesses(manifest: dict):
     """The behavioural quirks of SURVEY §0.3/§0.4, pinned as data."""
     w = {}
@@ -408,6 +475,7 @@ def main():
     for tag, spec, pde, n, seed in cases:
         run_case(tag, spec, pde, n, seed, manifest)
     check_loss_terms()
+    check_data_modes(manifest)
     quirk_witnesses(manifest)
     sampler_fixtures(manifest)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:

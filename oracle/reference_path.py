@@ -571,12 +571,18 @@ def _bc_fn(bc_type: str, params: Mapping[str, Any], dimension: int):
     return lambda x, t: torch.zeros_like(x[:, 0:1])
 
 
-def compute_loss_terms(pde: PdeSpec, model_fn, x: Tensor, t: Tensor) -> Dict[str, Tensor]:
-    """`PDEBase.compute_loss` (pdes/pde_base.py:1086-1235), forward mode, fixed weights.
+def compute_loss_terms(pde: PdeSpec, model_fn, x: Tensor, t: Tensor, observations: Optional[Mapping[str, Tensor]] = None,
+                       mode: str = "forward") -> Dict[str, Tensor]:
+    """`PDEBase.compute_loss` (pdes/pde_base.py:1086-1235), fixed weights.
 
     Includes the reference's behaviour that the "initial" entry added by
     `_setup_boundary_conditions` (pde_base.py:483-486) is ALSO enforced on the
     200 boundary points (pde_base.py:1129-1132).
+
+    `observations` ({"x", "t", "u"}) adds the data term of `_compute_data_loss` (pde_base.py:281-291); `mode` gates the
+    total as pde_base.py:1187-1233 does: "data_only" drops the physics terms from the total (they are still returned),
+    "inverse" / "data_only" / "data_augmented" force a positive data weight.  A trainable coefficient (inverse mode) is a
+    tensor with requires_grad in `pde.parameters`.
     """
     residual = compute_residual(pde, model_fn, x, t)
     lf = lambda e: apply_loss_fn(e, pde.loss_function, pde.huber_delta)  # noqa: E731
@@ -608,8 +614,15 @@ def compute_loss_terms(pde: PdeSpec, model_fn, x: Tensor, t: Tensor) -> Dict[str
         bw, iw = lw.get("boundary", 10.0), lw.get("initial", 10.0)
     else:
         rw, bw, iw = 1.0, 10.0, 10.0
-    total = rw * residual_loss + bw * boundary_loss + iw * initial_loss
-    return {"residual": residual_loss, "boundary": boundary_loss, "initial": initial_loss, "total": total}
+    data_loss = torch.tensor(0.0)
+    if observations:  # pde_base.py:281-291
+        data_loss = lf(model_fn(torch.cat([observations["x"], observations["t"]], dim=1)) - observations["u"])
+    data_weight = float(lw.get("data", 1.0)) if lw else 1.0  # _data_loss_weight, pde_base.py:328-336
+    active = 0.0 if mode == "data_only" else 1.0
+    if mode in ("inverse", "data_only", "data_augmented") and data_weight <= 0.0:
+        data_weight = 1.0
+    total = active * rw * residual_loss + active * bw * boundary_loss + active * iw * initial_loss + data_weight * data_loss
+    return {"residual": residual_loss, "boundary": boundary_loss, "initial": initial_loss, "data": data_loss, "total": total}
 
 
 def compute_loss_terms_heat(pde: PdeSpec, model_fn, x: Tensor, t: Tensor, num_boundary_points: Optional[int] = None,
@@ -656,6 +669,15 @@ def compute_loss_terms_heat(pde: PdeSpec, model_fn, x: Tensor, t: Tensor, num_bo
         rw, bw, iw = 1.0, 10.0, 10.0
     total = rw * residual_loss + bw * boundary_loss + iw * initial_loss
     return {"residual": residual_loss, "boundary": boundary_loss, "initial": initial_loss, "total": total}
+
+
+def rar_probabilities(pde: PdeSpec, model_fn, x_pool: Tensor, t_pool: Tensor) -> Tensor:
+    """The sampling weights of `PDEBase._sample_residual_based` (pdes/pde_base.py:912-930) on a given candidate pool:
+    |r| + 1e-8, normalised.  (The pool itself is `sample_uniform(4 N)`, the draw `torch.multinomial`.)"""
+    residuals = compute_residual(pde, model_fn, x_pool.detach().requires_grad_(True), t_pool.detach().requires_grad_(True))
+    mag = torch.abs(residuals.detach()).squeeze()
+    probs = mag + 1e-8
+    return probs / probs.sum()
 
 
 def sample_stratified(pde: PdeSpec, num_points: int) -> Tuple[Tensor, Tensor]:

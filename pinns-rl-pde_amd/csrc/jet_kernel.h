@@ -89,6 +89,8 @@ struct KernelArgs {
   long long det_stride;                     // deterministic mode: the gradient / loss pointers above point into row 0 of a
                                             // [grid][det_stride] slab and workgroup b adds (plainly) into row b; 0 = atomics
   int det_mask;                             // two-level flush (det_stride < 0): rows - 1, a power of two minus one
+  int flush_store;                          // det_stride > 0 only: the end-of-kernel flush writes this workgroup's row with plain
+                                            // STORES (every address exactly once; no memset of the slab beforehand)
 };
 
 // Gradient / loss accumulation at the end of a workgroup (or per tile for layers beyond the persistent ones): float
@@ -102,6 +104,11 @@ __device__ __forceinline__ long long det_row_offset(const KernelArgs& a) {
   return a.det_stride >= 0 ? (long long)blockIdx.x * a.det_stride : (long long)(blockIdx.x & a.det_mask) * -a.det_stride;
 }
 __device__ __forceinline__ void grad_add(float* p, float v, long long off) { atomicAdd(p + off, v); }
+// end-of-kernel flush: `store` (uniform) = this workgroup owns the row and writes each address once
+__device__ __forceinline__ void grad_put(float* p, float v, long long off, bool store) {
+  if (store) p[off] = v;
+  else atomicAdd(p + off, v);
+}
 
 // Every kernel of this family may use the whole 160 KB LDS of a CU as dynamic shared memory.  The attribute is set
 // ONCE per (kernel, device) — not per launch: it is a driver call on the launch path, and it is not allowed while

@@ -407,14 +407,14 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 template <int OFF, int NMAX, int NPT>
-__device__ __forceinline__ void flush_rows(const f32x16 (&pt)[NPT], const LayerDev& Ly, const Lane& L, long long doff) {
+__device__ __forceinline__ void flush_rows(const f32x16 (&pt)[NPT], const LayerDev& Ly, const Lane& L, long long doff, bool store = false) {
   if (!Ly.dW || L.wave * 32 >= Ly.out_dim) return;
   float* base = Ly.dW + (long long)(L.wave * 32 + 4 * L.lh) * Ly.ld + L.ln;
 #pragma unroll
   for (int kt = 0; kt < NMAX; ++kt) {
     if (kt * 32 + L.ln < Ly.in_dim) {  // in_dim may end inside a k-tile (e.g. 24 Fourier features)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) grad_add(base + (long long)((r & 3) + 8 * (r >> 2)) * Ly.ld + kt * 32, pt[OFF + kt][r], doff);
+      for (int r = 0; r < 16; ++r) grad_put(base + (long long)((r & 3) + 8 * (r >> 2)) * Ly.ld + kt * 32, pt[OFF + kt][r], doff, store);
     }
   }
 }
@@ -798,37 +798,46 @@ __global__ __launch_bounds__(kThreads, 1) void jet_kernel_wide(const KernelArgs 
 
   // ---- one flush per workgroup ----
   const long long doff = det_row_offset(a);  // deterministic mode: this workgroup's own slab row
+  // Store flush (a.flush_store; networks whose MFMA layers are all persistent): the workgroup owns row blockIdx.x of a
+  // [grid][stride] slab and WRITES it — 160 KB of gradient tiles at the store rate instead of the memory-side atomic
+  // rate (one 256-byte wave-instruction per ~50 ns per CU: 32 us on the critical path of the last workgroups), no memset
+  // of the slab; a fixed-order row sum follows (pinn_abi.hip::wide_rows_reduce).
+  const bool st = a.flush_store != 0;
   if (a.mode == MODE_PDE && a.loss_sum && L.wave == 0) {
     float sacc = L.lh == 0 ? ploss : 0.0f;
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-    if (tid == 0) grad_add(a.loss_sum, sacc, doff);
+    if (tid == 0) grad_put(a.loss_sum, sacc, doff, st);
   }
   if constexpr (BWD) {
     if (net.db_out && L.wave == 0) {
       float g = L.lh == 0 ? pdb_out : 0.0f;
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) g += __shfl_xor(g, o);
-      if (tid == 0) grad_add(net.db_out, g, doff);
+      if (tid == 0) grad_put(net.db_out, g, doff, st);
     }
     if (net.enc == ENC_LINEAR && net.d_encW && tid < net.enc_out) {
 #pragma unroll
       for (int cc = 0; cc < kMaxDin; ++cc)
-        if (cc < din) grad_add(net.d_encW + tid * din + cc, pl[(kPersist + cc) * hmax + tid], doff);
-      if (net.d_encb) grad_add(net.d_encb + tid, pl[(kPersist + kMaxDin) * hmax + tid], doff);
+        if (cc < din) grad_put(net.d_encW + tid * din + cc, pl[(kPersist + cc) * hmax + tid], doff, st);
+      if (net.d_encb) grad_put(net.d_encb + tid, pl[(kPersist + kMaxDin) * hmax + tid], doff, st);
     }
     if (net.dw_out) {  // dwo[wave][row][r]: rows 0,1 of a wave are the two point halves of lh = 0; 2,3 of lh = 1
       const int f = ft * 32 + acc_row(tid & 15, L.lh);
-      if (f < net.h_last) grad_add(net.dw_out + f, dwo[tid], doff);  // two lanes (point halves) per feature: a + b == b + a
+      if (st) {  // the two lanes (point halves) of a feature: one of them stores the pair's sum
+        if (f < net.h_last && (tid & 16) == 0) net.dw_out[doff + f] = dwo[tid] + dwo[tid ^ 16];
+      } else if (f < net.h_last) {
+        grad_add(net.dw_out + f, dwo[tid], doff);  // two lanes (point halves) per feature: a + b == b + a
+      }
     }
 #pragma unroll
     for (int p = 0; p < kPersist; ++p) {
       if (p < nl) {
         const LayerDev Lp = uniform_layer(net.layer[p]);
-        if (Lp.db && tid < Lp.out_dim) grad_add(Lp.db + tid, pl[p * hmax + tid], doff);
-        if (p == 0) flush_rows<0, NA0, NPT>(pt, Lp, L, doff);
-        else if (p == 1) flush_rows<NA0, NKT, NPT>(pt, Lp, L, doff);
-        else flush_rows<NA0 + NKT, NKT, NPT>(pt, Lp, L, doff);
+        if (Lp.db && tid < Lp.out_dim) grad_put(Lp.db + tid, pl[p * hmax + tid], doff, st);
+        if (p == 0) flush_rows<0, NA0, NPT>(pt, Lp, L, doff, st);
+        else if (p == 1) flush_rows<NA0, NKT, NPT>(pt, Lp, L, doff, st);
+        else flush_rows<NA0 + NKT, NKT, NPT>(pt, Lp, L, doff, st);
       }
     }
     PINN_STAMP(ST_BWD_FLUSH);

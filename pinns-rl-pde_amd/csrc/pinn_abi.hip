@@ -143,6 +143,14 @@ static bool build_wide(const PinnNetDesc* d, const float* const* w, float* const
   return true;
 }
 
+static bool wide_store_flush_on() {  // PINN_WIDE_STORE_FLUSH=0: the two-level atomic flush everywhere (experiments), read once
+  static const bool v = [] {
+    const char* e = getenv("PINN_WIDE_STORE_FLUSH");
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
+
 // ---- deterministic mode of the fused kernel -------------------------------------------------------------------------
 // Every gradient / loss pointer of the NetDev is redirected into row 0 of a [grid][stride] slab in the workspace;
 // workgroup b adds into row b with plain (non-atomic) adds, and this kernel then sums the rows of every element in
@@ -162,6 +170,40 @@ __global__ void wide_det_reduce(const DetTable tab, const float* slab, int rows)
     float s = 0.0f;
     for (int b = 0; b < rows; ++b) s += slab[(size_t)b * tab.stride + tab.off[it] + e];
     tab.user[it][e] += s;
+  }
+}
+
+// Store flush (KernelArgs::flush_store): every workgroup has WRITTEN its row; user[e] += sum over rows in row order.
+// A block sums 128 consecutive elements (32 threads x 16 bytes) over 8 interleaved row groups and combines them through
+// LDS in a fixed order: 42 MB of rows at ~4 TB/s instead of 256 dependent loads per thread.
+__global__ __launch_bounds__(256) void wide_rows_reduce(const DetTable tab, const float* slab, int rows) {
+  __shared__ float part[8][128];
+  const unsigned it = blockIdx.y;
+  const unsigned cnt4 = (tab.cnt[it] + 3u) & ~3u;  // rows are padded to 4 floats per target (det_slot)
+  const int el = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  for (unsigned e0 = blockIdx.x * 128u; e0 < cnt4; e0 += gridDim.x * 128u) {
+    const unsigned e = e0 + 4u * el;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (e < cnt4) {
+      const float* src = slab + tab.off[it] + e;
+#pragma unroll 8
+      for (int b = rg; b < rows; b += 8) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)b * tab.stride);
+        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+      }
+    }
+    part[rg][4 * el + 0] = s0;
+    part[rg][4 * el + 1] = s1;
+    part[rg][4 * el + 2] = s2;
+    part[rg][4 * el + 3] = s3;
+    __syncthreads();
+    if (threadIdx.x < 128 && e0 + threadIdx.x < tab.cnt[it]) {
+      float t = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += part[g][threadIdx.x];
+      tab.user[it][e0 + threadIdx.x] += t;
+    }
+    __syncthreads();
   }
 }
 
@@ -306,10 +348,15 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
     // slab and a small launch sums the rows into the caller's tensors: 32 instead of 256 workgroups contend for an
     // address.  Measured on the headline launch (kernel + memset + row sum, events around the call): direct atomics
     // 0.554 ms, 2 rows 0.553, 4 rows 0.549, 8 rows 0.543, 16 rows 0.545, 32 rows 0.550, 64 rows 0.567.
+    // Networks whose MFMA layers all keep their weight-gradient tiles in registers (n_layers <= kPersist: nothing is
+    // flushed inside the tile loop) take the STORE flush instead, in both modes: one slab row per workgroup, written
+    // with plain stores, then wide_rows_reduce.  The last workgroups of a launch no longer spend 32 us adding 160 KB
+    // at the memory-side atomic rate, and the slab needs no memset (jet_kernel_wide.h, end of the kernel).
     const int shared_rows = kFlushRows;
     const bool det_flag = (net->flags & PINN_FLAG_DETERMINISTIC) != 0;
-    const bool two_level = !det_flag && bwd && grid > shared_rows;
-    const bool det = det_flag || two_level;
+    const bool store_flush = bwd && a.net.n_layers <= kPersist && wide_store_flush_on();
+    const bool two_level = !det_flag && bwd && grid > shared_rows && !store_flush;
+    const bool det = det_flag || two_level || store_flush;
     const int slab_rows = two_level ? shared_rows : grid;
     const size_t tape_floats = bwd ? (size_t)jet_tape_floats_per_wg(K, a.net.n_layers, 1) * grid : 0;
     size_t need = tape_floats * sizeof(float);
@@ -336,12 +383,19 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
       dt.stride = stride;  // rows are as wide as the sizing pass said, whatever subset of targets this call has
       a.det_stride = two_level ? -(long long)stride : (long long)stride;
       a.det_mask = slab_rows - 1;
-      const hipError_t em = hipMemsetAsync(slab, 0, (size_t)stride * slab_rows * sizeof(float), static_cast<hipStream_t>(stream));
-      if (em != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)em, hipGetErrorString(em));
+      a.flush_store = store_flush ? 1 : 0;
+      if (!store_flush) {
+        const hipError_t em = hipMemsetAsync(slab, 0, (size_t)stride * slab_rows * sizeof(float), static_cast<hipStream_t>(stream));
+        if (em != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)em, hipGetErrorString(em));
+      }
     }
     hipError_t e = dispatch_wide(nt, nx, a, bwd, grid, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)e, hipGetErrorString(e));
-    if (det && dt.n > 0) {
+    if (det && dt.n > 0 && store_flush) {
+      hipLaunchKernelGGL(wide_rows_reduce, dim3(136, dt.n), dim3(256), 0, static_cast<hipStream_t>(stream), dt, slab, slab_rows);
+      e = hipGetLastError();
+      if (e != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)e, hipGetErrorString(e));
+    } else if (det && dt.n > 0) {
       hipLaunchKernelGGL(wide_det_reduce, dim3(32, dt.n), dim3(256), 0, static_cast<hipStream_t>(stream), dt, slab, slab_rows);
       e = hipGetLastError();
       if (e != hipSuccess) return fail(PINN_ERR_HIP, "HIP error %d: %s", (int)e, hipGetErrorString(e));
@@ -429,7 +483,7 @@ size_t pinn_workspace_bytes(const PinnNetDesc* net, int64_t N, int32_t time_orde
   if (use_wide(net, nullptr, nullptr, K, bwd, &n)) {
     const size_t grid = (size_t)wide_grid(n, K, N, bwd);
     size_t bytes = bwd ? (size_t)jet_tape_floats_per_wg(K, n.n_layers, 1) * sizeof(float) * grid : 0;
-    if (net->flags & PINN_FLAG_DETERMINISTIC) {
+    if ((net->flags & PINN_FLAG_DETERMINISTIC) || (bwd && n.n_layers <= kPersist && wide_store_flush_on())) {
       DetTable dt;
       float* lprobe = nullptr;
       det_redirect(n, lprobe, nullptr, dt);

@@ -435,18 +435,32 @@ class PDEBase:
         if model is None:
             return self._sample_uniform(num_points)
         x_pool, t_pool = self._sample_uniform(num_points * 4)
+        probs = self._residual_sampling_probabilities(model, x_pool, t_pool)
+        if probs is None:
+            return self._sample_uniform(num_points)
+        sel = torch.multinomial(probs, num_points, replacement=True)
+        return x_pool[sel].detach(), t_pool[sel].detach()
+
+    def _residual_sampling_probabilities(self, model, x_pool: torch.Tensor, t_pool: torch.Tensor) -> Optional[torch.Tensor]:
+        """p_n = (|r_n| + 1e-8) / sum_m (|r_m| + 1e-8) of pde_base.py:917-930.  ONE forward-only launch gives the residual
+        field AND its normaliser: with the l1 reduction the fused kernel's loss sum is sum |r| (no extra pass over the
+        4N pool).  Trainable coefficients take the jets + torch epilogue path."""
         try:
             with torch.no_grad():
-                r = self.compute_residual(model, x_pool, t_pool)
-            mag = torch.abs(r.detach()).squeeze()
+                if self._has_trainable_coefficients() or not hasattr(model, "program"):
+                    mag = torch.abs(self.compute_residual(model, x_pool, t_pool).detach()).reshape(-1)
+                    total = mag.sum()
+                else:
+                    _jets_of(model)
+                    coefs = [float(c.detach()) if isinstance(c, torch.Tensor) else float(c) for c in self._coefficients()]
+                    pd_l1 = _E.pde_desc(self.KIND, self.dimension, coefs, "mae", 1.0)
+                    r, total = _E.residual_forward(model.program(), pd_l1, x_pool.detach().to(self.device), t_pool.detach().to(self.device))
+                    mag = torch.abs(r).reshape(-1)
         except NotImplementedError:
             raise
         except Exception:
-            return self._sample_uniform(num_points)
-        probs = mag + 1e-8
-        probs = probs / probs.sum()
-        sel = torch.multinomial(probs, num_points, replacement=True)
-        return x_pool[sel].detach(), t_pool[sel].detach()
+            return None
+        return (mag + 1e-8) / (total.reshape(()) + 1e-8 * mag.numel())
 
     def generate_collocation_points(self, num_points: int, strategy: str = "uniform", **kwargs):
         if strategy == "uniform":

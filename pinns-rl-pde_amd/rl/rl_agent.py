@@ -71,6 +71,34 @@ class RLAgent:  # rl_agent.py:139-229, 557-566
                 return self.policy_net(state.to(self.device)).view(1, -1)
         return torch.rand(1, 1, device=self.device)
 
+    def action_probabilities(self, state: torch.Tensor) -> torch.Tensor:
+        """Device-side form of `select_action` + the sampler's `abs / sum` (pde_base.py:1021-1030) with FIXED shapes and no
+        host round trip, so that the adaptive sampler can sit inside a captured step: a (G*G,) probability vector that is
+        |Q| / sum |Q| on the exploit branch and all mass on grid cell 0 on the explore branch — exactly what the
+        reference's (1, 1) explore action does to its one-category multinomial.  The branch is chosen on the
+        device: `rand > epsilon` with epsilon read from `self.epsilon` (a float, or a device scalar once
+        `epsilon_tensor()` has been called).  The policy network keeps its mode (train: dropout active, as in the
+        reference, which never calls `.eval()`)."""
+        state = state.to(self.device)
+        with torch.no_grad():
+            q = self.policy_net(state).reshape(-1).abs()
+            probs = q / q.sum()
+            eps = self._eps_dev if getattr(self, "_eps_dev", None) is not None else torch.full((), float(self.epsilon), device=self.device)
+            exploit = torch.rand((), device=self.device) > eps
+            onehot = torch.zeros_like(probs)
+            onehot[0] = 1.0
+            return torch.where(exploit, probs, onehot)
+
+    def epsilon_tensor(self) -> torch.Tensor:
+        """Move the exploration rate to a device scalar (decayed on the device by `update_epsilon_device`)."""
+        if getattr(self, "_eps_dev", None) is None:
+            self._eps_dev = torch.full((), float(self.epsilon), device=self.device)
+        return self._eps_dev
+
+    def update_epsilon_device(self) -> None:  # update_epsilon without a host value (rl_agent.py:557-566)
+        e = self.epsilon_tensor()
+        e.copy_(torch.clamp(e * self.epsilon_decay, min=self.epsilon_end))
+
     def update_epsilon(self, epoch: int = None):
         self.epsilon = max(self.epsilon_end, self.epsilon * self.epsilon_decay)
         return self.epsilon

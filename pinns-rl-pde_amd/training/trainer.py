@@ -295,8 +295,6 @@ class PDETrainer:
             return "optimizer is not Adam"
         if self.use_adaptive_weights:
             return "adaptive loss weights"
-        if self.process_group is not None:
-            return "data-parallel training"
         if self.rl_agent is not None or getattr(tc, "collocation_distribution", "uniform") not in ("uniform", "stratified"):
             return "host-driven sampler (RL / residual-based)"
         if type(self.pde).compute_loss is not PDEBase.compute_loss:
@@ -377,6 +375,8 @@ class PDETrainer:
         pd = self.pde._pde_desc()
         n, N = F["n"], x.shape[0]
         loss_name, delta = self.pde._loss_function_name(), self.pde._huber_delta()
+        if self.process_group is not None:
+            return self._manual_launches_dp(x, t, F, prog, pd, n, N, loss_name, delta)
 
         def boundary_chain(grad, summary):
             u = _E.jets_forward(prog, F["x_all"], F["t_all"], 0, 0)
@@ -409,6 +409,31 @@ class PDETrainer:
                           beta2=F["betas"][1], eps=F["eps"], weight_decay=F["wd"],
                           max_norm=float(self.config.training.gradient_clipping))
 
+    def _manual_launches_dp(self, x, t, F, prog, pd, n, N, loss_name, delta):
+        """The same launch list under a process group (one process per GPU): this rank's contiguous shard of the
+        identically-sampled batch goes through the residual launch with the GLOBAL 1/N, the replicated boundary /
+        initial chain contributes with weight 1/world, ONE in-place sum all-reduce carries [flat gradient || residual
+        loss sum], and every rank applies the same clip + Adam update: replicas stay bit-identical."""
+        pg = self.process_group
+        world = torch.distributed.get_world_size(pg)
+        xs, ts, _ = _D.shard_points(x, t, pg)
+        terms_dp = F.get("terms_dp")
+        if terms_dp is None or F.get("terms_dp_world") != world:
+            terms_dp = [(lo, hi, tg, w / world) for lo, hi, tg, w in F["terms"]]
+            F["terms_dp"], F["terms_dp_world"] = terms_dp, world
+        F["grad"].zero_()
+        _E.residual_loss_grad(prog, pd, xs, ts, F["rw"] / float(N), F["grad"][:n], loss_sum=F["grad"][n : n + 1])
+        u = _E.jets_forward(prog, F["x_all"], F["t_all"], 0, 0)
+        _E.point_losses(u[0], terms_dp, loss_name, delta, F["term_losses"], F["cot"][0])
+        _E.jets_backward(prog, F["x_all"], F["t_all"], 0, 0, F["cot"], F["grad"][:n])
+        torch.distributed.all_reduce(F["grad"], op=torch.distributed.ReduceOp.SUM, group=pg)
+        # loss terms with the unscaled weights and the reduced (global) residual sum, for the step's summary
+        _E.point_losses(u[0], F["terms"], loss_name, delta, F["term_losses"], F["cot"][0], residual_sum=F["grad"][n : n + 1],
+                        residual_scale=1.0 / float(N), residual_weight=F["rw"], n_boundary_terms=F["n_bc"], summary4=F["summary"])
+        _E.adam_clip_step(F["theta"], F["grad"], F["m"], F["v"], F["lr"], F["step"], F["scratch"], beta1=F["betas"][0],
+                          beta2=F["betas"][1], eps=F["eps"], weight_decay=F["wd"],
+                          max_norm=float(self.config.training.gradient_clipping))
+
     def _manual_losses(self, static: bool = False):
         """{residual, boundary, initial, total} of the last manual step.  `static=True` hands out views of the persistent
         summary buffer (what a captured graph refreshes in place); otherwise independent copies, so that a caller may
@@ -430,6 +455,8 @@ class PDETrainer:
         `train` refreshes after each scheduler step.  Steps the fixed sequence does not cover (L-BFGS, adaptive
         weights, RL / residual-based sampling, data-parallel, PDEs with their own compute_loss) raise."""
         why = self._manual_step_unsupported()
+        if why is None and self.process_group is not None:
+            why = "data-parallel training (a collective inside the capture)"
         if why is not None:
             raise NotImplementedError(f"graph capture covers the plain Adam step only ({why})")
         self._build_flat_state()

@@ -421,3 +421,45 @@ def test_bench_multi_rank_rehearsal(scaling, dev):
     assert out["config"]["global_points"] == (n if scaling == "strong" else 2 * n)
     assert out["config"]["points_per_gpu"] == (n - n // 2 if scaling == "strong" else n)
     assert "all-reduce" in out["config"]["collective"]
+
+
+def test_rar_probabilities_match_the_oracle(dev):
+    """Value-level check of residual-based sampling (pde_base.py:895-935): on a FIXED 4N pool the device-side weights
+    (|r| from the forward-only launch, normaliser from the same launch's l1 reduction) equal the oracle's."""
+    import oracle as O
+
+    cfg, model, pde, (spec, ps, sd, a, m) = build("burgers_fourier_4x128", dev)
+    torch.manual_seed(11)
+    xp, tp = O.sample_uniform(ps, 4 * 900)
+    want = O.rar_probabilities(ps, lambda z: O.network_forward(spec, sd, z), xp, tp)
+    got = pde._residual_sampling_probabilities(model, xp.to(dev), tp.to(dev))
+    assert got.shape == want.shape and abs(float(got.sum()) - 1.0) <= 1e-5
+    assert rel_l2(got.cpu(), want) <= 1e-5, f"{rel_l2(got.cpu(), want):.2e}"
+
+
+def test_dqn_grid_scores_on_the_device_match_the_oracle(dev):
+    """The DQN policy network scoring the G x G sampling grid on the device (eval mode: dropout off, so the scores are
+    deterministic) equals oracle.dqn_forward on the same theta_0; and the device-side action selection reproduces the two
+    branches of RLAgent.select_action without a host round trip."""
+    import oracle as O
+    from pinnrl_amd.rl import RLAgent
+
+    torch.manual_seed(3)
+    agent = RLAgent(state_dim=2, action_dim=1, hidden_dim=64, device=dev)
+    sd = {k: v.detach().cpu() for k, v in agent.policy_net.state_dict().items()}
+    G = 100
+    xs, ts = torch.linspace(-1, 1, G), torch.linspace(0, 1, G)
+    X, T = torch.meshgrid(xs, ts, indexing="ij")
+    pts = torch.stack([X.flatten(), T.flatten()], 1)
+    agent.policy_net.eval()
+    with torch.no_grad():
+        got = agent.policy_net(pts.to(dev)).reshape(-1).cpu()
+    want = O.dqn_forward(sd, pts, training=False).reshape(-1)
+    assert rel_l2(got, want) <= 1e-5
+    # device-side selection: epsilon = 0 -> |Q| over the grid (normalised); epsilon = 1 -> all mass on cell 0
+    agent.epsilon = 0.0
+    p0 = agent.action_probabilities(pts.to(dev))
+    assert rel_l2(p0.cpu(), want.abs() / want.abs().sum()) <= 1e-5
+    agent.epsilon = 1.0
+    p1 = agent.action_probabilities(pts.to(dev))
+    assert float(p1[0]) == 1.0 and float(p1[1:].abs().sum()) == 0.0

@@ -64,7 +64,7 @@ def _worker(rank, world, port, out):
     red = D.all_reduce_gradients(list(model.parameters()), scalars=[losses["residual"]])
     flat = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
     theta = torch.cat([p.detach().flatten() for p in model.parameters()])
-    out.put((rank, flat, float(red[0]), theta))
+    out.put((rank, flat.numpy(), float(red[0]), theta.numpy()))  # by value: shared-memory tensor handles die with this process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,6 +81,7 @@ def test_two_rank_data_parallel_equals_full_batch():
         p.join(60)
         assert p.exitcode == 0
     (_, g0, L0, th0), (_, g1, L1, th1) = res
+    g0, g1, th0, th1 = (torch.from_numpy(v) for v in (g0, g1, th0, th1))
     assert torch.equal(th0, th1), "broadcast_parameters must make replicas identical"
     assert torch.equal(g0, g1) and L0 == L1, "every rank must hold the same reduced gradient and loss"
     # single-process full batch from rank 0's parameters
@@ -206,3 +207,167 @@ def test_inverse_mode_shard_uses_the_global_count():
     full = pde._residual_loss(None, torch.zeros(30, 1), torch.zeros(30, 1))
     part = pde._residual_loss(None, x, x, n_total=30)
     assert torch.allclose(part, (r[:10] ** 2).sum() / 30) and torch.allclose(full, (r**2).mean())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The autograd-free launch list under a process group (VERDICT r2 #5a): `_manual_launches_dp` with an oracle-backed
+# stand-in for the five engine entry points it calls.  What is verified is the host logic: shard + global 1/N, the
+# replicated boundary / initial chain weighted 1/world, ONE all-reduce of [grad || loss sum] before the clip + Adam
+# update, replicas bit-identical, and equality with the single-process launch list on the full batch.
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeProg:
+    def __init__(self, names, tensors):
+        self.names, self.tensors = names, tensors
+        self.trainable = [p.requires_grad for p in tensors]
+
+    def grad_layout(self):
+        offs, n = [], 0
+        for p, tr in zip(self.tensors, self.trainable):
+            offs.append(n if tr else -1)
+            if tr:
+                n += (p.numel() + 3) // 4 * 4
+        return offs, n
+
+
+class _FakeEngine:
+    """CPU restatement of the engine calls of `PDETrainer._manual_launches` on top of the oracle (mse losses only)."""
+
+    spec = None
+    pde_spec = O.PdeSpec(name="burgers", parameters={"nu": 0.01 / math.pi})
+
+    @classmethod
+    def _fn(cls, prog):
+        return lambda inp: O.network_forward(cls.spec, dict(zip(prog.names, prog.tensors)), inp)
+
+    @staticmethod
+    def _accumulate(prog, flat, grads):
+        offs, _ = prog.grad_layout()
+        live = [(p, o) for p, o in zip(prog.tensors, offs) if o >= 0]
+        for (p, o), g in zip(live, grads):
+            flat[o : o + p.numel()] += g.reshape(-1)
+
+    @classmethod
+    def residual_loss_grad(cls, prog, pd, x, t, scale, flat, want_residual=False, loss_sum=None):
+        ps = [p for p, tr in zip(prog.tensors, prog.trainable) if tr]
+        with torch.enable_grad():
+            r = O.compute_residual(cls.pde_spec, cls._fn(prog), x, t)
+            L = (r**2).sum()
+            gs = torch.autograd.grad(L * scale, ps)
+        cls._accumulate(prog, flat, gs)
+        loss_sum += L.detach()
+        return None, loss_sum
+
+    @classmethod
+    def jets_forward(cls, prog, x, t, nt, nx):
+        with torch.no_grad():
+            return cls._fn(prog)(torch.cat([x, t], 1)).reshape(1, -1)
+
+    @classmethod
+    def jets_backward(cls, prog, x, t, nt, nx, cot, flat):
+        ps = [p for p, tr in zip(prog.tensors, prog.trainable) if tr]
+        with torch.enable_grad():
+            u = cls._fn(prog)(torch.cat([x, t], 1)).reshape(-1)
+            gs = torch.autograd.grad((u * cot[0]).sum(), ps)
+        cls._accumulate(prog, flat, gs)
+
+    @staticmethod
+    def point_losses(u, terms, loss, huber_delta, term_losses, cot, residual_sum=None, residual_scale=0.0, residual_weight=0.0,
+                     n_boundary_terms=0, summary4=None):  # csrc/train_kernels.hip::point_loss_kernel, mse
+        cot.zero_()
+        for k, (lo, hi, target, w) in enumerate(terms):
+            e = u[lo:hi] - target
+            term_losses[k] = (e**2).mean()
+            cot[lo:hi] += w * 2.0 * e / (hi - lo)
+        if summary4 is not None:
+            res = residual_sum[0] * residual_scale
+            summary4[0] = res
+            summary4[1] = term_losses[:n_boundary_terms].sum()
+            summary4[2] = term_losses[n_boundary_terms : len(terms)].sum()
+            summary4[3] = residual_weight * res + sum(w * term_losses[k] for k, (_, _, _, w) in enumerate(terms))
+
+    @staticmethod
+    def adam_clip_step(theta, grads, m, v, lr, step, scratch, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, max_norm=0.0,
+                       grad_norm_out=None):  # clip_grad_norm_ + torch.optim.Adam on the flat buffers
+        n = theta.numel()
+        g = grads[:n].clone()
+        if max_norm > 0:
+            g *= min(1.0, max_norm / (float(g.norm()) + 1e-6))
+        if weight_decay:
+            g += weight_decay * theta
+        step += 1
+        k = float(step)
+        m.mul_(beta1).add_(g, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        theta -= float(lr) / (1 - beta1**k) * m / (v.sqrt() / math.sqrt(1 - beta2**k) + eps)
+
+
+class _ManualOracleModel(OracleModel):
+    def program(self):
+        return _FakeProg(self.names, list(self.params))
+
+
+def _manual_trainer(spec, sd, group):
+    from pinnrl_amd.config import Config, TrainingConfig
+    from pinnrl_amd.training import PDETrainer
+    from pinnrl_amd.training import trainer as T
+
+    _FakeEngine.spec = spec
+    T._E = _FakeEngine  # the stand-in under the same host code
+    cfg = Config.__new__(Config)
+    cfg.device = torch.device("cpu")
+    cfg.training = TrainingConfig(learning_rate=1e-3, gradient_clipping=1.0)
+    model = _ManualOracleModel(spec, sd)
+    tr = PDETrainer(model, _pde(), {}, cfg, device=torch.device("cpu"), process_group=group)
+    assert tr._manual_step_unsupported() is None
+    tr._build_flat_state()
+    return model, tr
+
+
+def _manual_dp_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    spec, pde_s, sd, a, m = load_case("burgers_fourier_3x32")
+    torch.manual_seed(400 + rank)  # replicas start different: the trainer broadcasts
+    model, tr = _manual_trainer(spec, {k: v + 0.01 * torch.randn_like(v) for k, v in sd.items()}, dist.group.WORLD)
+    theta0 = torch.cat([p.detach().flatten() for p in model.parameters()])
+    x, t = torch.from_numpy(a["x"])[:101], torch.from_numpy(a["t"])[:101]
+    for _ in range(2):
+        losses = tr.train_step(x, t)
+    theta2 = torch.cat([p.detach().flatten() for p in model.parameters()])
+    out.put((rank, theta0.numpy(), theta2.numpy(), [float(losses[k]) for k in ("residual", "boundary", "initial", "total")]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_manual_launch_list_under_a_process_group():
+    world, port = 2, 29933 + os.getpid() % 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_manual_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda z: z[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, a0, a2, la), (_, b0, b2, lb) = res
+    a0, a2, b0, b2 = (torch.from_numpy(v) for v in (a0, a2, b0, b2))
+    assert torch.equal(a0, b0) and torch.equal(a2, b2), "replicas must stay bit-identical on the manual data-parallel step"
+    assert la == lb, "every rank reports the same (global) loss terms"
+    assert not torch.equal(a0, a2)
+    # single process, same launch list, full batch, from the same theta_0
+    spec, pde_s, sd, a, m = load_case("burgers_fourier_3x32")
+    model, tr = _manual_trainer(spec, sd, None)
+    with torch.no_grad():
+        off = 0
+        for p in model.parameters():
+            p.copy_(a0[off : off + p.numel()].view_as(p))
+            off += p.numel()
+    x, t = torch.from_numpy(a["x"])[:101], torch.from_numpy(a["t"])[:101]
+    for _ in range(2):
+        single = tr.train_step(x, t)
+    want = torch.cat([p.detach().flatten() for p in model.parameters()])
+    assert rel_l2(a2, want) < 1e-5
+    for k, v in zip(("residual", "boundary", "initial", "total"), la):
+        assert abs(v - float(single[k])) <= 1e-5 * abs(float(single[k])), k

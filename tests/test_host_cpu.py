@@ -47,11 +47,12 @@ def test_descriptor_queries_without_a_gpu():
     nbytes = lib.pinn_workspace_bytes(ctypes.byref(prog.desc), 49729, 1, 2, 1)
     row = (8192 + 128 + 16384 + 128 + 16384 + 128 + 128 + 4 + 4) * 4  # one slab row: every gradient tensor (rounded up to 4) + loss
     tape = 4 * 4 * 16 * 256 * 4 * 256  # (3 layers + encoding) x K = 4 streams x 16 regs x 256 threads x 4 B x 256 CUs
-    assert nbytes == tape + 8 * row  # + the 8 shared rows of the two-level gradient flush
-    # deterministic mode stays on the fused kernel: + one slab row per workgroup (41 473 gradient floats in 8 tensors, each
-    # rounded up to 4, + the loss sum); forward-only calls then need the rows for the loss alone... same sizing
-    prog.set_deterministic(True)
+    # + one slab row per workgroup: the store flush (every MFMA layer of this network keeps its gradient tiles in
+    # registers, so each workgroup WRITES its row at the end and a row sum follows; 41 473 gradient floats in 8 tensors,
+    # each rounded up to 4, + the loss sum).  Deterministic mode: the same rows, the same sizing
     slab = row * 256
+    assert nbytes == tape + slab
+    prog.set_deterministic(True)
     assert lib.pinn_workspace_bytes(ctypes.byref(prog.desc), 49729, 1, 2, 1) == tape + slab
     assert lib.pinn_workspace_bytes(ctypes.byref(prog.desc), 49729, 1, 2, 0) == slab
     prog.set_deterministic(False)
