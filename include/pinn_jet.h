@@ -192,6 +192,17 @@ int pinn_point_losses(const float* u, int32_t n_total, int32_t n_terms, const in
                       float* term_losses, float* cotangent, const float* residual_sum, float residual_scale,
                       float residual_weight, int32_t n_boundary_terms, float* summary4, void* stream);
 
+/* The general form of pinn_point_losses, for PDEs whose compute_loss reads more than the value stream on its boundary
+ * points (HeatEquation.compute_loss, pinnrl/pdes/heat_equation.py:375-623: periodic boundary conditions on u AND du/dx at
+ * paired wall points): jets is the (n_streams x n_total) output of pinn_jet_forward; term k reads stream stream_of[k] and is
+ * either  l(J[n] - targets[k][n - lo[k]])  or — pair_offset[k] != 0, targets[k] may be null —  l(J[n] - J[n + pair_offset[k]])
+ * for n in [lo[k], hi[k]) (the partner range must not overlap it).  cotangent: (n_streams x n_total), overwritten: the
+ * jet_cotangents of pinn_jet_backward.  Everything else as pinn_point_losses. */
+int pinn_jet_losses(const float* jets, int32_t n_streams, int32_t n_total, int32_t n_terms, const int32_t* lo, const int32_t* hi,
+                    const int32_t* stream_of, const int32_t* pair_offset, const float* const* targets, const float* weights,
+                    int32_t loss, float huber_delta, float* term_losses, float* cotangent, const float* residual_sum,
+                    float residual_scale, float residual_weight, int32_t n_boundary_terms, float* summary4, void* stream);
+
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) (skipped when max_norm <= 0) followed by
  * torch.optim.Adam(lr, (beta1, beta2), eps, weight_decay).step() on ONE flat fp32 buffer of n elements.
  * lr and step are DEVICE scalars (step = number of steps taken so far, incremented by the call) so that a captured

@@ -29,7 +29,7 @@ LOSS = {"mse": 0, "mae": 1, "huber": 2}
 EXPORTS = (
     "pinn_abi_version", "pinn_last_error", "pinn_build_info", "pinn_num_tensors", "pinn_pde_streams",
     "pinn_workspace_bytes", "pinn_jet_forward", "pinn_jet_backward", "pinn_residual_forward", "pinn_residual_backward",
-    "pinn_residual_loss_grad", "pinn_point_losses", "pinn_adam_clip_step",
+    "pinn_residual_loss_grad", "pinn_point_losses", "pinn_jet_losses", "pinn_adam_clip_step",
 )
 
 
@@ -113,6 +113,9 @@ def load():
                                                 P(vp), vp, sz, vp]
         lib.pinn_point_losses.restype = ctypes.c_int
         lib.pinn_point_losses.argtypes = [vp, i32, i32, P(i32), P(i32), P(vp), P(f32), i32, f32, vp, vp, vp, f32, f32, i32, vp, vp]
+        lib.pinn_jet_losses.restype = ctypes.c_int
+        lib.pinn_jet_losses.argtypes = [vp, i32, i32, i32, P(i32), P(i32), P(i32), P(i32), P(vp), P(f32), i32, f32, vp, vp, vp, f32, f32,
+                                        i32, vp, vp]
         lib.pinn_adam_clip_step.restype = ctypes.c_int
         lib.pinn_adam_clip_step.argtypes = [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, vp, vp, vp, vp]
         if lib.pinn_abi_version() != PINN_ABI_VERSION:

@@ -79,6 +79,63 @@ __global__ __launch_bounds__(256) void point_loss_kernel(const float* u, PointTe
   }
 }
 
+// The general form: jets J[stream][n] (K x n_total), term k on stream `stream[k]`, either against a target array or —
+// pair[k] != 0 — as the difference of two point ranges, d_i = J[s][lo + i] - J[s][lo + pair + i] (periodic boundary
+// conditions: value and d/dx at paired wall points, heat_equation.py:420-445).  cot is K x n_total, overwritten.
+struct JetTerms {
+  int n_terms;
+  int lo[PINN_MAX_POINT_TERMS], hi[PINN_MAX_POINT_TERMS], stream[PINN_MAX_POINT_TERMS], pair[PINN_MAX_POINT_TERMS];
+  const float* target[PINN_MAX_POINT_TERMS];
+  float weight[PINN_MAX_POINT_TERMS];
+  int loss;
+  float huber_delta;
+};
+
+__global__ __launch_bounds__(256) void jet_loss_kernel(const float* J, int K, JetTerms p, int n_total, float* losses, float* cot,
+                                                       const float* residual_sum, float residual_scale, float residual_weight,
+                                                       int n_boundary_terms, float* summary4) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  for (int n = tid; n < K * n_total; n += 256) cot[n] = 0.0f;
+  __syncthreads();
+  for (int k = 0; k < p.n_terms; ++k) {
+    const int cnt = p.hi[k] - p.lo[k];
+    const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;
+    const float* Js = J + (long long)p.stream[k] * n_total;
+    float* cs = cot + (long long)p.stream[k] * n_total;
+    float acc = 0.0f;
+    for (int n = p.lo[k] + tid; n < p.hi[k]; n += 256) {
+      float dl;
+      const float other = p.pair[k] ? Js[n + p.pair[k]] : p.target[k][n - p.lo[k]];
+      acc += loss_val(p.loss, p.huber_delta, Js[n] - other, &dl);
+      const float c = p.weight[k] * dl * inv;
+      cs[n] += c;  // terms run one after another and a term's two ranges are disjoint: no two threads share an address
+      if (p.pair[k]) cs[n + p.pair[k]] -= c;
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) red[tid] += red[tid + s];
+      __syncthreads();
+    }
+    if (tid == 0) losses[k] = red[0] * inv;
+    __syncthreads();
+  }
+  if (tid == 0 && summary4) {
+    const float res = residual_sum ? residual_sum[0] * residual_scale : 0.0f;
+    float bnd = 0.0f, ini = 0.0f, tot = residual_weight * res;
+    for (int k = 0; k < p.n_terms; ++k) {
+      if (k < n_boundary_terms) bnd += losses[k];
+      else ini += losses[k];
+      tot += p.weight[k] * losses[k];
+    }
+    summary4[0] = res;
+    summary4[1] = bnd;
+    summary4[2] = ini;
+    summary4[3] = tot;
+  }
+}
+
 constexpr int kNormBlocks = 64;
 
 // partial sums of squares in a fixed order (deterministic): block b sums elements b*256+tid, +64*256, ...
@@ -151,6 +208,35 @@ int pinn_point_losses(const float* u, int32_t n_total, int32_t n_terms, const in
   p.huber_delta = huber_delta;
   hipLaunchKernelGGL(point_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), u, p, n_total, term_losses, cotangent,
                      residual_sum, residual_scale, residual_weight, n_boundary_terms, summary4);
+  return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
+}
+
+int pinn_jet_losses(const float* jets, int32_t n_streams, int32_t n_total, int32_t n_terms, const int32_t* lo, const int32_t* hi,
+                    const int32_t* stream_of, const int32_t* pair_offset, const float* const* targets, const float* weights,
+                    int32_t loss, float huber_delta, float* term_losses, float* cotangent, const float* residual_sum,
+                    float residual_scale, float residual_weight, int32_t n_boundary_terms, float* summary4, void* stream) {
+  if (!jets || !lo || !hi || !stream_of || !pair_offset || !targets || !weights || !term_losses || !cotangent) return PINN_ERR_BAD_DESC;
+  if (n_terms < 0 || n_terms > PINN_MAX_POINT_TERMS || n_total < 0 || n_streams < 1 || n_streams > PINN_MAX_STREAMS) return PINN_ERR_BAD_DESC;
+  JetTerms p;
+  p.n_terms = n_terms;
+  for (int k = 0; k < n_terms; ++k) {
+    if (lo[k] < 0 || hi[k] < lo[k] || hi[k] > n_total || stream_of[k] < 0 || stream_of[k] >= n_streams) return PINN_ERR_BAD_DESC;
+    if (pair_offset[k]) {  // the partner range must lie inside the jets and must not overlap the term's own range
+      if (pair_offset[k] < hi[k] - lo[k] || hi[k] + pair_offset[k] > n_total) return PINN_ERR_BAD_DESC;
+    } else if (!targets[k]) {
+      return PINN_ERR_BAD_DESC;
+    }
+    p.lo[k] = lo[k];
+    p.hi[k] = hi[k];
+    p.stream[k] = stream_of[k];
+    p.pair[k] = pair_offset[k];
+    p.target[k] = targets[k];
+    p.weight[k] = weights[k];
+  }
+  p.loss = loss;
+  p.huber_delta = huber_delta;
+  hipLaunchKernelGGL(jet_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), jets, n_streams, p, n_total, term_losses,
+                     cotangent, residual_sum, residual_scale, residual_weight, n_boundary_terms, summary4);
   return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
 }
 

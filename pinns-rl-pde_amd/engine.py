@@ -324,6 +324,30 @@ def point_losses(u: Tensor, terms: Sequence[Tuple[int, int, Tensor, float]], los
                                          summary4.data_ptr() if summary4 is not None else None, _stream(dev)))
 
 
+def jet_losses(jets: Tensor, terms: Sequence[Tuple[int, int, int, int, Optional[Tensor], float]], loss: str, huber_delta: float,
+               term_losses: Tensor, cot: Tensor, residual_sum: Optional[Tensor] = None, residual_scale: float = 0.0,
+               residual_weight: float = 0.0, n_boundary_terms: int = 0, summary4: Optional[Tensor] = None) -> None:
+    """General form of `point_losses` on (K, n) jets.  term k = (lo, hi, stream, pair_offset, target | None, weight):
+    mean l(J[stream, lo:hi] - target) or, with pair_offset != 0, mean l(J[stream, lo:hi] - J[stream, lo+pair : hi+pair])
+    (periodic boundary pairs); cot (K, n) is overwritten with the cotangents of the jets.  One launch."""
+    lib = _lib.load()
+    dev = _require_device(jets, term_losses, cot, *[t[4] for t in terms if t[4] is not None])
+    assert jets.dim() == 2 and jets.is_contiguous() and cot.shape == jets.shape and cot.is_contiguous()
+    n = len(terms)
+    lo = (ctypes.c_int32 * n)(*[int(t[0]) for t in terms])
+    hi = (ctypes.c_int32 * n)(*[int(t[1]) for t in terms])
+    st = (ctypes.c_int32 * n)(*[int(t[2]) for t in terms])
+    pr = (ctypes.c_int32 * n)(*[int(t[3]) for t in terms])
+    tg = (ctypes.c_void_p * n)(*[t[4].data_ptr() if t[4] is not None else None for t in terms])
+    w = (ctypes.c_float * n)(*[float(t[5]) for t in terms])
+    with torch.cuda.device(dev):
+        _lib.check(lib.pinn_jet_losses(jets.data_ptr(), jets.shape[0], jets.shape[1], n, lo, hi, st, pr, tg, w, _lib.LOSS.get(loss, 0),
+                                       float(huber_delta), term_losses.data_ptr(), cot.data_ptr(),
+                                       residual_sum.data_ptr() if residual_sum is not None else None, float(residual_scale),
+                                       float(residual_weight), int(n_boundary_terms),
+                                       summary4.data_ptr() if summary4 is not None else None, _stream(dev)))
+
+
 def adam_clip_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: Tensor, step: Tensor,
                    scratch: Tensor, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                    weight_decay: float = 0.0, max_norm: float = 0.0, grad_norm_out: Optional[Tensor] = None) -> None:

@@ -202,6 +202,38 @@ class HeatEquation(PDEBase):
         return self._compose_losses(residual_loss, boundary_loss, initial_loss, smoothness_loss,
                                     self._compute_data_loss(model), aux_scale)
 
+    def _manual_chain(self, n_batch: int):
+        """heat_equation.py:375-540 as a launch-list description (see PDEBase._manual_chain), 1-D: ONE (u, u_t, u_x) jet
+        launch over [left wall | right wall | initial points]; the periodic boundary loss is two PAIRED terms (value and
+        d/dx of the two walls at the same clustered times), the initial loss a target term."""
+        if self.dimension != 1:
+            raise NotImplementedError("HeatEquation launch list: 1-D only (the >= 2-D boundary points are re-drawn every step)")
+        dev = self.device
+        nbp = self._num_points("num_boundary_points", 10, n_batch)
+        nip = self._num_points("num_initial_points", 5, n_batch)
+        t_max = self.config.time_domain[1]
+        t_early = t_max * 0.01
+        n_early = max(nbp // 4, 1)
+        tb = torch.cat([torch.linspace(0, t_early, n_early, device=dev),
+                        torch.linspace(t_early, t_max, nbp - n_early, device=dev)]).reshape(-1, 1)
+        x_lo, x_hi = self.config.domain[0]
+        xb = (x_hi - x_lo) * 0.1
+        xi = torch.cat([torch.linspace(x_lo, x_lo + xb, nip // 4, device=dev),
+                        torch.linspace(x_lo + xb, x_hi - xb, nip // 2, device=dev),
+                        torch.linspace(x_hi - xb, x_hi, nip // 4, device=dev)]).reshape(-1, 1)
+        ti = torch.zeros(xi.shape[0], 1, device=dev)
+        if "initial" in self.boundary_conditions:
+            target = self.boundary_conditions["initial"](xi, ti)
+        else:
+            target = torch.sin(self.config.initial_condition.get("frequency", 2.0) * torch.pi * xi)
+        lw = self._loss_weights()
+        bw, iw = (lw.get("boundary", 10.0), lw.get("initial", 10.0)) if lw else (10.0, 10.0)
+        x_all = torch.cat([torch.full((nbp, 1), x_lo, device=dev), torch.full((nbp, 1), x_hi, device=dev), xi], 0).contiguous()
+        t_all = torch.cat([tb, tb, ti], 0).contiguous()
+        terms = [(0, nbp, 0, nbp, None, float(bw)), (0, nbp, 2, nbp, None, float(bw)),  # u and u_x (stream 2 of [u, u_t, u_x])
+                 (2 * nbp, 2 * nbp + xi.shape[0], 0, 0, target.reshape(-1).float().contiguous(), float(iw))]
+        return {"x": x_all, "t": t_all, "nt": 1, "nx": 1, "terms": terms, "n_bc": 2}
+
     def _compute_smoothness_loss(self, model, x, t):  # heat_equation.py:625-650
         eps = 1e-4
         x, t = x.detach(), t.detach()

@@ -506,6 +506,39 @@ class PDEBase:
             self.rl_agent.update_epsilon(len(self.collocation_history))
         return x.contiguous(), t.contiguous()
 
+    def _sample_adaptive_device(self, num_points: int):
+        """`_sample_adaptive` without a host round trip (no `.item()`, no history copy), for the autograd-free / captured
+        step: the agent's `action_probabilities` (fixed-shape form of select_action + abs / sum, explore branch = all mass
+        on grid cell 0, as the reference's one-category multinomial), multinomial, jitter, clamp on the device; epsilon
+        decays on the device from the second call on (pde_base.py:1068-1071).  The collocation history of the host
+        version (one CPU copy of every batch) is not kept."""
+        dev = self.device
+        G = min(100, max(10, int(np.sqrt(num_points))))
+        cache = getattr(self, "_adaptive_grid", None)
+        if cache is None or cache[0] != (G, str(dev)):
+            grids = [torch.linspace(self.domain[d][0], self.domain[d][1], G, device=dev) for d in range(self.dimension)]
+            grids.append(torch.linspace(self.time_domain[0], self.time_domain[1], G, device=dev))
+            mesh = torch.meshgrid(*grids, indexing="ij")
+            cache = ((G, str(dev)), torch.stack([g.flatten() for g in mesh], dim=1).contiguous())
+            self._adaptive_grid = cache
+        points = cache[1]
+        probs = self.rl_agent.action_probabilities(points)
+        idx = torch.multinomial(probs, min(num_points, len(points)), replacement=True)
+        sel = points[idx]
+        if len(sel) < num_points:
+            extra = torch.randint(0, len(sel), (num_points - len(sel),), device=dev)
+            sel = torch.cat([sel, sel[extra]], dim=0)
+        noise_scale = min(0.01, min((self.domain[d][1] - self.domain[d][0]) / G for d in range(self.dimension)),
+                          (self.time_domain[1] - self.time_domain[0]) / G)
+        sel = sel + torch.randn_like(sel) * noise_scale
+        cols = [torch.clamp(sel[:, d], self.domain[d][0], self.domain[d][1]) for d in range(self.dimension)]
+        tcol = torch.clamp(sel[:, -1], self.time_domain[0], self.time_domain[1])
+        self._adaptive_calls = getattr(self, "_adaptive_calls", 0) + 1
+        if self._adaptive_calls > 1:
+            self.rl_agent.update_epsilon_device()
+        x = torch.stack(cols, dim=1).contiguous()
+        return x, tcol.reshape(-1, 1).contiguous()
+
     # ---------------------------------------------------------------- losses (pde_base.py:1086-1235)
     def _residual_loss(self, model, x: torch.Tensor, t: torch.Tensor, n_total: Optional[int] = None) -> torch.Tensor:
         """mean_n l(r_n): residual, reduction AND dL/dtheta in one launch when the coefficients are plain numbers."""
@@ -574,6 +607,21 @@ class PDEBase:
         inp_i = torch.cat([xi, ti], dim=1)
         self._bc_ic_points = (dev, (inp_b, xb, tb, inp_i, xi, ti))
         return self._bc_ic_points[1]
+
+    def _manual_chain(self, n_batch: int) -> Dict[str, Any]:
+        """The boundary / initial part of `compute_loss` (pde_base.py:1101-1165) as data for the autograd-free step
+        (`PDETrainer._manual_launches`): fixed points, the stream set to evaluate on them, and loss terms
+        (lo, hi, stream, pair_offset, target | None, weight) in the form of `engine.jet_losses`; the first `n_bc` terms are the
+        boundary loss, the rest the initial loss."""
+        inp_b, xb, tb, inp_i, xi, ti = self._boundary_and_initial_points()
+        nb, ni = xb.shape[0], xi.shape[0]
+        lw = self._loss_weights()
+        bw, iw = (lw.get("boundary", 10.0), lw.get("initial", 10.0)) if lw else (10.0, 10.0)
+        terms = [(0, nb, 0, 0, fn(xb, tb).reshape(-1).float().contiguous(), float(bw)) for fn in self.boundary_conditions.values()]
+        ic_fn = self.boundary_conditions.get("initial") or self._create_boundary_condition("initial", self.config.initial_condition)
+        terms.append((nb, nb + ni, 0, 0, ic_fn(xi, ti).reshape(-1).float().contiguous(), float(iw)))
+        return {"x": torch.cat([xb, xi], 0).contiguous(), "t": torch.cat([tb, ti], 0).contiguous(), "nt": 0, "nx": 0,
+                "terms": terms, "n_bc": len(terms) - 1}
 
     def _compose_losses(self, residual_loss, boundary_loss, initial_loss, smoothness_loss, data_loss, aux_scale=1.0):
         """The weighting / mode gating tail shared by every `compute_loss` (pde_base.py:1168-1235, heat_equation.py:543-623)."""

@@ -85,8 +85,7 @@ class RLAgent:  # rl_agent.py:139-229, 557-566
             probs = q / q.sum()
             eps = self._eps_dev if getattr(self, "_eps_dev", None) is not None else torch.full((), float(self.epsilon), device=self.device)
             exploit = torch.rand((), device=self.device) > eps
-            onehot = torch.zeros_like(probs)
-            onehot[0] = 1.0
+            onehot = (torch.arange(probs.numel(), device=self.device) == 0).to(probs.dtype)  # no host scalar: capturable
             return torch.where(exploit, probs, onehot)
 
     def epsilon_tensor(self) -> torch.Tensor:

@@ -169,6 +169,11 @@ class PDETrainer:
     # ---------------------------------------------------------------- one step
     def _sample(self, batch_size: int):
         strategy = "adaptive" if self.rl_agent is not None else self.config.training.collocation_distribution
+        if strategy == "adaptive" and getattr(self, "_flat", None) is not None and hasattr(self.pde, "_sample_adaptive_device"):
+            # the autograd-free step samples without a host round trip (device-side action selection and epsilon decay)
+            if getattr(self.pde, "rl_agent", None) is None:
+                self.pde.rl_agent = self.rl_agent
+            return self.pde._sample_adaptive_device(batch_size)
         kw = {"model": self.model} if strategy == "residual_based" else {}
         x, t = self.pde.generate_collocation_points(batch_size, strategy=strategy, **kw)
         return x.to(self.device), t.to(self.device)
@@ -295,10 +300,15 @@ class PDETrainer:
             return "optimizer is not Adam"
         if self.use_adaptive_weights:
             return "adaptive loss weights"
-        if self.rl_agent is not None or getattr(tc, "collocation_distribution", "uniform") not in ("uniform", "stratified"):
-            return "host-driven sampler (RL / residual-based)"
-        if type(self.pde).compute_loss is not PDEBase.compute_loss:
-            return f"{type(self.pde).__name__} overrides compute_loss"
+        if self.rl_agent is not None and not hasattr(self.rl_agent, "action_probabilities"):
+            return "RL agent without a device-side action selection"
+        if getattr(tc, "collocation_distribution", "uniform") not in ("uniform", "stratified", "residual_based"):
+            return "unknown sampler"
+        own_loss = type(self.pde).compute_loss is not PDEBase.compute_loss
+        if own_loss and type(self.pde)._manual_chain is PDEBase._manual_chain:
+            return f"{type(self.pde).__name__} overrides compute_loss without a launch-list form (_manual_chain)"
+        if own_loss and (self.pde._loss_weights() or {}).get("smoothness", 0.0) > 0:
+            return "smoothness term"
         if self.pde.dimension != 1 or self.pde._has_trainable_coefficients() or self.pde._training_mode() != "forward":
             return "multi-dimensional, inverse or data-driven mode"
         if getattr(self.pde, "observation_data", None):
@@ -333,32 +343,35 @@ class PDETrainer:
                 p.data = view
         g = self.optimizer.param_groups[0]
         self.optimizer._opt_called = True  # the flat Adam kernel steps from now on; schedulers only read / write param_groups
-        pde = self.pde
-        inp_b, xb, tb, inp_i, xi, ti = pde._boundary_and_initial_points()
-        x_all = torch.cat([xb, xi], 0).contiguous()
-        t_all = torch.cat([tb, ti], 0).contiguous()
-        nb, ni = xb.shape[0], xi.shape[0]
-        lw = pde._loss_weights()
-        if lw:
-            rw, bw, iw = lw.get("pde", lw.get("residual", 1.0)), lw.get("boundary", 10.0), lw.get("initial", 10.0)
-        else:
-            rw, bw, iw = 1.0, 10.0, 10.0
-        terms = [(0, nb, fn(xb, tb).reshape(-1).float().contiguous(), float(bw)) for fn in pde.boundary_conditions.values()]
-        ic_fn = pde.boundary_conditions.get("initial") or pde._create_boundary_condition("initial", pde.config.initial_condition)
-        terms.append((nb, nb + ni, ic_fn(xi, ti).reshape(-1).float().contiguous(), float(iw)))
+        lw = self.pde._loss_weights()
+        rw = lw.get("pde", lw.get("residual", 1.0)) if lw else 1.0
         self._flat = {
             "theta": theta, "m": m, "v": v, "grad": torch.zeros(n + 4, dtype=torch.float32, device=dev),
             "step": torch.tensor([steps], dtype=torch.float32, device=dev),
             "lr": torch.tensor([g["lr"]], dtype=torch.float32, device=dev),
-            "scratch": torch.zeros(64, dtype=torch.float32, device=dev), "n": n,
-            "x_all": x_all, "t_all": t_all, "terms": terms, "n_bc": len(terms) - 1, "rw": float(rw),
-            "term_losses": torch.zeros(len(terms), dtype=torch.float32, device=dev),
-            "cot": torch.zeros(1, nb + ni, dtype=torch.float32, device=dev),
+            "scratch": torch.zeros(64, dtype=torch.float32, device=dev), "n": n, "rw": float(rw), "chains": {},
             "grad_side": torch.zeros(n, dtype=torch.float32, device=dev),
             "summary": torch.zeros(4, dtype=torch.float32, device=dev),
             "betas": g["betas"], "eps": g["eps"], "wd": g["weight_decay"],
         }
         return self._flat
+
+    def _chain(self, n_batch: int, world: int = 1):
+        """The boundary / initial part of `compute_loss` as a launch-list description (`PDEBase._manual_chain`: fixed
+        evaluation points, stream set, loss terms), cached per batch length (HeatEquation sizes its point sets from it
+        when the config carries no counts) with its persistent buffers."""
+        F = self._flat
+        key = (int(n_batch), int(world))
+        ch = F["chains"].get(key)
+        if ch is None:
+            ch = dict(self.pde._manual_chain(int(n_batch)))
+            dev = self.device
+            K, npts = 1 + ch["nt"] + ch["nx"], ch["x"].shape[0]
+            ch["term_losses"] = torch.zeros(len(ch["terms"]), dtype=torch.float32, device=dev)
+            ch["cot"] = torch.zeros(K, npts, dtype=torch.float32, device=dev)
+            ch["terms_dp"] = [(lo, hi, st, pr, tg, w / world) for lo, hi, st, pr, tg, w in ch["terms"]]
+            F["chains"][key] = ch
+        return ch
 
     def _manual_launches(self, x, t, side=None):
         """One optimiser step as a fixed launch sequence, no autograd (pinnrl/training/trainer.py:686-698 with
@@ -378,12 +391,14 @@ class PDETrainer:
         if self.process_group is not None:
             return self._manual_launches_dp(x, t, F, prog, pd, n, N, loss_name, delta)
 
+        ch = self._chain(N)
+
         def boundary_chain(grad, summary):
-            u = _E.jets_forward(prog, F["x_all"], F["t_all"], 0, 0)
-            _E.point_losses(u[0], F["terms"], loss_name, delta, F["term_losses"], F["cot"][0],
-                            residual_sum=F["grad"][n : n + 1] if summary else None, residual_scale=1.0 / float(N),
-                            residual_weight=F["rw"], n_boundary_terms=F["n_bc"], summary4=F["summary"] if summary else None)
-            _E.jets_backward(prog, F["x_all"], F["t_all"], 0, 0, F["cot"], grad)
+            u = _E.jets_forward(prog, ch["x"], ch["t"], ch["nt"], ch["nx"])
+            _E.jet_losses(u, ch["terms"], loss_name, delta, ch["term_losses"], ch["cot"],
+                          residual_sum=F["grad"][n : n + 1] if summary else None, residual_scale=1.0 / float(N),
+                          residual_weight=F["rw"], n_boundary_terms=ch["n_bc"], summary4=F["summary"] if summary else None)
+            _E.jets_backward(prog, ch["x"], ch["t"], ch["nt"], ch["nx"], ch["cot"], grad)
             return u
 
         F["grad"].zero_()
@@ -403,8 +418,8 @@ class PDETrainer:
             F["grad"][:n].add_(F["grad_side"])
             # the {residual, boundary, initial, total} summary needs the residual launch's loss sum: the (3 us) loss-term
             # kernel runs once more here; it rewrites the same cotangents
-            _E.point_losses(u[0], F["terms"], loss_name, delta, F["term_losses"], F["cot"][0], residual_sum=F["grad"][n : n + 1],
-                            residual_scale=1.0 / float(N), residual_weight=F["rw"], n_boundary_terms=F["n_bc"], summary4=F["summary"])
+            _E.jet_losses(u, ch["terms"], loss_name, delta, ch["term_losses"], ch["cot"], residual_sum=F["grad"][n : n + 1],
+                          residual_scale=1.0 / float(N), residual_weight=F["rw"], n_boundary_terms=ch["n_bc"], summary4=F["summary"])
         _E.adam_clip_step(F["theta"], F["grad"], F["m"], F["v"], F["lr"], F["step"], F["scratch"], beta1=F["betas"][0],
                           beta2=F["betas"][1], eps=F["eps"], weight_decay=F["wd"],
                           max_norm=float(self.config.training.gradient_clipping))
@@ -417,19 +432,16 @@ class PDETrainer:
         pg = self.process_group
         world = torch.distributed.get_world_size(pg)
         xs, ts, _ = _D.shard_points(x, t, pg)
-        terms_dp = F.get("terms_dp")
-        if terms_dp is None or F.get("terms_dp_world") != world:
-            terms_dp = [(lo, hi, tg, w / world) for lo, hi, tg, w in F["terms"]]
-            F["terms_dp"], F["terms_dp_world"] = terms_dp, world
+        ch = self._chain(N, world)
         F["grad"].zero_()
         _E.residual_loss_grad(prog, pd, xs, ts, F["rw"] / float(N), F["grad"][:n], loss_sum=F["grad"][n : n + 1])
-        u = _E.jets_forward(prog, F["x_all"], F["t_all"], 0, 0)
-        _E.point_losses(u[0], terms_dp, loss_name, delta, F["term_losses"], F["cot"][0])
-        _E.jets_backward(prog, F["x_all"], F["t_all"], 0, 0, F["cot"], F["grad"][:n])
+        u = _E.jets_forward(prog, ch["x"], ch["t"], ch["nt"], ch["nx"])
+        _E.jet_losses(u, ch["terms_dp"], loss_name, delta, ch["term_losses"], ch["cot"])
+        _E.jets_backward(prog, ch["x"], ch["t"], ch["nt"], ch["nx"], ch["cot"], F["grad"][:n])
         torch.distributed.all_reduce(F["grad"], op=torch.distributed.ReduceOp.SUM, group=pg)
         # loss terms with the unscaled weights and the reduced (global) residual sum, for the step's summary
-        _E.point_losses(u[0], F["terms"], loss_name, delta, F["term_losses"], F["cot"][0], residual_sum=F["grad"][n : n + 1],
-                        residual_scale=1.0 / float(N), residual_weight=F["rw"], n_boundary_terms=F["n_bc"], summary4=F["summary"])
+        _E.jet_losses(u, ch["terms"], loss_name, delta, ch["term_losses"], ch["cot"], residual_sum=F["grad"][n : n + 1],
+                      residual_scale=1.0 / float(N), residual_weight=F["rw"], n_boundary_terms=ch["n_bc"], summary4=F["summary"])
         _E.adam_clip_step(F["theta"], F["grad"], F["m"], F["v"], F["lr"], F["step"], F["scratch"], beta1=F["betas"][0],
                           beta2=F["betas"][1], eps=F["eps"], weight_decay=F["wd"],
                           max_norm=float(self.config.training.gradient_clipping))

@@ -1,6 +1,7 @@
 """GPU tests of the drop-in Python surface (PINNModel / XxxEquation / PDETrainer) against the oracle."""
 
 import math
+import os
 
 import pytest
 import torch
@@ -463,3 +464,103 @@ def test_dqn_grid_scores_on_the_device_match_the_oracle(dev):
     agent.epsilon = 1.0
     p1 = agent.action_probabilities(pts.to(dev))
     assert float(p1[0]) == 1.0 and float(p1[1:].abs().sum()) == 0.0
+
+
+def test_heat_manual_step_matches_cpu_reference_path(dev):
+    """HeatEquation.compute_loss (BASELINE C1's PDE: periodic BC on u and du/dx, clustered points) through the autograd-free
+    launch list: theta after 1 / 3 / 10 Adam steps vs oracle.compute_loss_terms_heat + torch Adam on the CPU."""
+    import oracle as O
+    from pinnrl_amd.training import PDETrainer
+
+    cfg, model, pde, (spec, ps, sd, a, m) = build("heat_fourier_4x128", dev)
+    cfg.training.gradient_clipping = 1.0
+    cfg.training.learning_rate = 1e-3
+    trainer = PDETrainer(model, pde, {}, cfg, device=dev)
+    assert trainer._manual_step_unsupported() is None
+    trainer._build_flat_state()
+    params = {k: v.clone().requires_grad_(k != "model.fourier.B") for k, v in sd.items()}
+    names = [k for k in params if params[k].requires_grad]
+    opt = torch.optim.Adam([params[k] for k in names], lr=1e-3, weight_decay=0.0)
+    torch.manual_seed(5)
+    batches = [O.sample_uniform(ps, 400) for _ in range(10)]
+    for step, (xb, tb) in enumerate(batches, start=1):
+        losses = trainer.train_step(xb.to(dev), tb.to(dev))
+        opt.zero_grad()
+        want = O.compute_loss_terms_heat(ps, lambda z: O.network_forward(spec, params, z), xb, tb)
+        want["total"].backward()
+        torch.nn.utils.clip_grad_norm_([params[k] for k in names], 1.0)
+        opt.step()
+        for k in ("residual", "boundary", "initial", "total"):
+            assert abs(float(losses[k]) - float(want[k])) <= 5e-5 * abs(float(want[k])), (step, k)
+        if step in (1, 3, 10):
+            got = torch.cat([p.detach().flatten().cpu() for _, p in model.named_parameters()])
+            ref = torch.cat([params[k].detach().flatten() for k in names])
+            assert rel_l2(got, ref) <= 1e-5, f"theta after {step} steps: {rel_l2(got, ref):.2e}"
+
+
+def _small_config(tag, dev):
+    """Reduced-size stand-ins of BASELINE C1 / C3 / C4 (same PDE, architecture family, sampler) for the graphed-step test."""
+    import bench_configs as B
+    from pinnrl_amd import pdes as P
+    from pinnrl_amd.rl import RLAgent
+
+    torch.manual_seed(0)
+    if tag == "C1":
+        net = B.model("fourier", 64, 3, "tanh")
+        eq = B.pde(P.HeatEquation, [(0.0, 1.0)], (0.0, 1.0), {"alpha": 0.01}, {"type": "sine"})
+        return net, eq, None
+    if tag == "C3":
+        net = B.model("resnet", 128, 2, "tanh", num_blocks=2)
+        eq = B.pde(P.AllenCahnEquation, [(-1.0, 1.0)], (0.0, 1.0), {"epsilon": 0.01}, {"type": "tanh"})
+        agent = RLAgent(state_dim=2, action_dim=1, hidden_dim=64, device=dev)
+        agent.epsilon = 0.3
+        agent.policy_net.eval()  # dropout off: the eager and the captured run must score identically
+        eq.rl_agent = agent
+        return net, eq, agent
+    net = B.model("siren", 128, 3, "tanh", omega_0=30.0)
+    eq = B.pde(P.KdVEquation, [(-15.0, 15.0)], (0.0, 5.0), {"speed": 1.0}, {"type": "soliton"})
+    return net, eq, None
+
+
+@pytest.mark.parametrize("tag", ["C1", "C3", "C4"])
+def test_graph_captured_step_for_the_other_configurations(tag, dev):
+    """The captured step on the PDE / network / sampler families of BASELINE C1 (HeatEquation's own compute_loss), C3
+    (ResNet through the layer-major engine, DQN-adaptive sampling inside the step) and C4 (SIREN, third-order residual):
+    two replays move theta like two eager launch-list steps from the same theta_0 and the same RNG state."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from pinnrl_amd.config import Config, TrainingConfig
+    from pinnrl_amd.training import PDETrainer
+
+    thetas = []
+    for graphed in (False, True):
+        net, eq, agent = _small_config(tag, dev)
+        cfg = Config.__new__(Config)
+        cfg.device = dev
+        cfg.training = TrainingConfig(learning_rate=1e-3, gradient_clipping=1.0)
+        tr = PDETrainer(net, eq, {}, cfg, device=dev, rl_agent=agent)
+        assert tr._manual_step_unsupported() is None, tr._manual_step_unsupported()
+        tr._build_flat_state()
+        if agent is None:  # pin the batch: both runs see identical points (the adaptive sampler is seeded instead)
+            torch.manual_seed(1)
+            xb, tb = eq.generate_collocation_points(1000, strategy="uniform")
+            tr._sample = lambda n, xb=xb, tb=tb: (xb, tb)
+        if graphed:
+            replay, losses = tr.make_graphed_step(961, warmup=1)
+            torch.manual_seed(7)
+            for _ in range(2):
+                replay()
+            torch.cuda.synchronize()
+            assert math.isfinite(float(losses["total"]))
+        else:
+            x0, t0 = tr._sample(961)
+            tr.train_step(x0, t0)  # the warm-up step of the graphed run
+            torch.manual_seed(7)
+            for _ in range(2):
+                x0, t0 = tr._sample(961)
+                tr.train_step(x0, t0)
+        thetas.append(torch.cat([p.detach().flatten().cpu() for p in net.parameters()]))
+    if agent is None:
+        assert rel_l2(thetas[1], thetas[0]) <= 1e-5, f"{rel_l2(thetas[1], thetas[0]):.2e}"
+    else:  # device RNG inside a captured graph advances by its own offsets: same law, different draws
+        assert rel_l2(thetas[1], thetas[0]) <= 5e-2 and torch.isfinite(thetas[1]).all()

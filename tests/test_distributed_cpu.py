@@ -267,23 +267,24 @@ class _FakeEngine:
         ps = [p for p, tr in zip(prog.tensors, prog.trainable) if tr]
         with torch.enable_grad():
             u = cls._fn(prog)(torch.cat([x, t], 1)).reshape(-1)
-            gs = torch.autograd.grad((u * cot[0]).sum(), ps)
+            gs = torch.autograd.grad((u * cot[0]).sum(), ps)  # cot: (1, n)
         cls._accumulate(prog, flat, gs)
 
     @staticmethod
-    def point_losses(u, terms, loss, huber_delta, term_losses, cot, residual_sum=None, residual_scale=0.0, residual_weight=0.0,
-                     n_boundary_terms=0, summary4=None):  # csrc/train_kernels.hip::point_loss_kernel, mse
+    def jet_losses(jets, terms, loss, huber_delta, term_losses, cot, residual_sum=None, residual_scale=0.0, residual_weight=0.0,
+                   n_boundary_terms=0, summary4=None):  # csrc/train_kernels.hip::jet_loss_kernel, mse, target terms on the value stream
         cot.zero_()
-        for k, (lo, hi, target, w) in enumerate(terms):
-            e = u[lo:hi] - target
+        for k, (lo, hi, stream, pair, target, w) in enumerate(terms):
+            assert stream == 0 and pair == 0
+            e = jets[0, lo:hi] - target
             term_losses[k] = (e**2).mean()
-            cot[lo:hi] += w * 2.0 * e / (hi - lo)
+            cot[0, lo:hi] += w * 2.0 * e / (hi - lo)
         if summary4 is not None:
             res = residual_sum[0] * residual_scale
             summary4[0] = res
             summary4[1] = term_losses[:n_boundary_terms].sum()
             summary4[2] = term_losses[n_boundary_terms : len(terms)].sum()
-            summary4[3] = residual_weight * res + sum(w * term_losses[k] for k, (_, _, _, w) in enumerate(terms))
+            summary4[3] = residual_weight * res + sum(t[5] * term_losses[k] for k, t in enumerate(terms))
 
     @staticmethod
     def adam_clip_step(theta, grads, m, v, lr, step, scratch, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, max_norm=0.0,
