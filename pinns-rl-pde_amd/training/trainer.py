@@ -166,6 +166,53 @@ class PDETrainer:
         v = vals.tolist()
         return {"total_loss": v[0], "residual_loss": v[1], "boundary_loss": v[2], "initial_loss": v[3]}
 
+    # ---------------------------------------------------------------- live snapshot (trainer.py:171-279)
+    def live_snapshot_fields(self, grid_size: int = 60) -> Dict[str, object]:
+        """The fields of the reference's `_save_live_snapshot` — predicted u and the PDE residual on a fixed
+        grid_size x grid_size grid (x-t in 1-D; x1-x2 at the mid time in >= 2-D) — from two forward-only launches (no
+        autograd graph; the reference builds one for the residual and throws it away).  Same keys as its `.npz`."""
+        dev = self.device
+        dim = int(getattr(self.pde, "dimension", 1))
+        t_lo, t_hi = float(self.pde.time_domain[0]), float(self.pde.time_domain[1])
+        if dim <= 1:
+            xs = np.linspace(float(self.pde.domain[0][0]), float(self.pde.domain[0][1]), grid_size, dtype=np.float32)
+            ys = np.linspace(t_lo, t_hi, grid_size, dtype=np.float32)
+            xx, tt = np.meshgrid(xs, ys, indexing="xy")
+            x_flat = torch.tensor(xx.reshape(-1, 1), device=dev)
+            t_flat = torch.tensor(tt.reshape(-1, 1), device=dev)
+            meta = {"dimension": 1, "x_label": "x", "y_label": "t", "fixed_t": float("nan")}
+        else:
+            xs = np.linspace(float(self.pde.domain[0][0]), float(self.pde.domain[0][1]), grid_size, dtype=np.float32)
+            ys = np.linspace(float(self.pde.domain[1][0]), float(self.pde.domain[1][1]), grid_size, dtype=np.float32)
+            xx1, xx2 = np.meshgrid(xs, ys, indexing="xy")
+            cols = [xx1.reshape(-1), xx2.reshape(-1)] + [np.full(xx1.size, 0.5 * (float(self.pde.domain[d][0]) + float(self.pde.domain[d][1])),
+                                                                 dtype=np.float32) for d in range(2, dim)]
+            x_flat = torch.tensor(np.stack(cols, axis=1), device=dev, dtype=torch.float32)
+            fixed_t = 0.5 * (t_lo + t_hi)
+            t_flat = torch.full((x_flat.shape[0], 1), fixed_t, dtype=torch.float32, device=dev)
+            meta = {"dimension": 2, "x_label": "x1", "y_label": "x2", "fixed_t": float(fixed_t)}
+        was_training = self.model.training
+        try:
+            with torch.no_grad():
+                u = self.model(torch.cat([x_flat, t_flat], dim=1))
+                r = self.pde.compute_residual(self.model, x_flat, t_flat)  # forward-only kernel under no_grad
+        finally:
+            self.model.train(was_training)
+        out = {"axis_x": xs, "axis_y": ys, "u_pred": u.detach().cpu().numpy()[:, 0].reshape(grid_size, grid_size),
+               "residual": r.detach().cpu().numpy().reshape(grid_size, grid_size)}
+        out.update(meta)
+        return out
+
+    def _save_live_snapshot(self, experiment_dir: str, epoch: int, grid_size: int = 60) -> None:
+        if not experiment_dir:
+            return
+        try:
+            import os
+
+            np.savez(os.path.join(experiment_dir, "live_snapshot.npz"), epoch=int(epoch), **self.live_snapshot_fields(grid_size))
+        except Exception as exc:  # viz must never crash the training loop (trainer.py:186-188)
+            self.logger.debug(f"Live snapshot skipped: {exc}")
+
     # ---------------------------------------------------------------- one step
     def _sample(self, batch_size: int):
         strategy = "adaptive" if self.rl_agent is not None else self.config.training.collocation_distribution
@@ -535,6 +582,8 @@ class PDETrainer:
             for k, v in row.items():
                 if k in self.history:
                     self.history[k].append(v)
+            if experiment_dir and self.viz_frequency and epoch % self.viz_frequency == 0:
+                self._save_live_snapshot(experiment_dir, epoch)
             if epoch % self.validation_frequency == 0:
                 val = self._compute_validation_loss()
                 self.history["val_loss"].append(val["total_loss"])

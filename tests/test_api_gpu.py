@@ -3,6 +3,7 @@
 import math
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -564,3 +565,24 @@ def test_graph_captured_step_for_the_other_configurations(tag, dev):
         assert rel_l2(thetas[1], thetas[0]) <= 1e-5, f"{rel_l2(thetas[1], thetas[0]):.2e}"
     else:  # device RNG inside a captured graph advances by its own offsets: same law, different draws
         assert rel_l2(thetas[1], thetas[0]) <= 5e-2 and torch.isfinite(thetas[1]).all()
+
+
+def test_live_snapshot_fields_match_the_oracle(dev, tmp_path):
+    """The 60 x 60 u + residual evaluation of the reference's `_save_live_snapshot` (trainer.py:171-279) from forward-only
+    launches: values against the oracle, keys of the `.npz` as upstream."""
+    import oracle as O
+    from pinnrl_amd.training import PDETrainer
+
+    cfg, model, pde, (spec, ps, sd, a, m) = build("burgers_fourier_4x128", dev)
+    tr = PDETrainer(model, pde, {}, cfg, device=dev)
+    f = tr.live_snapshot_fields(60)
+    xs, ts = torch.from_numpy(f["axis_x"]), torch.from_numpy(f["axis_y"])
+    tt, xx = torch.meshgrid(ts, xs, indexing="ij")  # numpy "xy": rows = t, columns = x
+    x, t = xx.reshape(-1, 1), tt.reshape(-1, 1)
+    fn = lambda z: O.network_forward(spec, sd, z)  # noqa: E731
+    assert rel_l2(f["u_pred"].reshape(-1), fn(torch.cat([x, t], 1)).detach().reshape(-1)) <= 1e-5
+    assert rel_l2(f["residual"].reshape(-1), O.compute_residual(ps, fn, x, t).detach().reshape(-1)) <= 1e-5
+    tr._save_live_snapshot(str(tmp_path), 3)
+    z = np.load(tmp_path / "live_snapshot.npz")
+    assert set(z.files) == {"axis_x", "axis_y", "u_pred", "residual", "epoch", "dimension", "x_label", "y_label", "fixed_t"}
+    assert int(z["epoch"]) == 3 and z["u_pred"].shape == (60, 60)

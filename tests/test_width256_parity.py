@@ -10,7 +10,7 @@ import math
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -71,7 +71,8 @@ def test_stream_serial_two_tile_kernel(arch, pde_name, kw, dev):
     keys = [k for k in g_o if k in g]
     got = torch.cat([g[k].flatten().cpu() for k in keys])
     want = torch.cat([g_o[k].flatten() for k in keys])
-    assert rel_l2(got, want) <= TOL, f"{rel_l2(got, want):.3e}"
+    e_g = rel_l2(got, want, label="gradient", tol=TOL)
+    assert e_g <= TOL, f"{e_g:.3e}"
 
 
 def test_resnet_width_256(dev):
@@ -158,19 +159,22 @@ def _full(arch, pde_name, dim=1, n=256, **kw):
 ])
 def test_baseline_networks_full_depth_gradient(name, arch, pde_name, dim, kw, dev):
     """the weight gradient of the five BASELINE networks at their full depth and width, through the
-    C ABI, against the fp64 oracle (not a self-comparison).  SIREN's third derivatives carry the reference's own
-    fp32-vs-fp64 noise of ~3e-6 per 4 layers (tests/golden/manifest.json), hence 2e-5 for the 8-layer case."""
+    C ABI, against the fp64 oracle (not a self-comparison).  All five at the north-star tolerance: the 8-layer SIREN
+    (third derivatives, omega_0 = 30) measures 3.4e-6 / 4.7e-6 on residual / gradient through the fused kernels and
+    4.4e-6 / 5.9e-6 unfused (profiles/parity_r03.md; round 2 held it to 2e-5 without recording the margin)."""
     spec, pde, sd, x, t = _full(arch, pde_name, dim, **kw)
     r, L, g = _gpu(spec, pde, sd, x, t, dev)
     r_o, L_o, g_o = _oracle64(spec, pde, sd, x, t)
-    tol = 2 * TOL if arch == "siren" else TOL
-    assert rel_l2(r, r_o) <= tol, f"{name}: residual {rel_l2(r, r_o):.3e}"
-    assert abs(L - float(L_o)) <= tol * abs(float(L_o))
+    tol = TOL
+    e_r = rel_l2(r, r_o, label="residual", tol=tol)
+    assert e_r <= tol, f"{name}: residual {e_r:.3e}"
+    assert rel_err(L, float(L_o), label="loss", tol=tol) <= tol
     keys = [k for k in g_o if k in g]
     assert len(keys) == len(g_o)
     got = torch.cat([g[k].flatten().cpu() for k in keys])
     want = torch.cat([g_o[k].flatten() for k in keys])
-    assert rel_l2(got, want) <= tol, f"{name}: gradient {rel_l2(got, want):.3e}"
+    e_g = rel_l2(got, want, label="gradient", tol=tol)
+    assert e_g <= tol, f"{name}: gradient {e_g:.3e}"
     for k in keys:  # and tensor by tensor, so that one small tensor cannot hide behind a large one
         if float(g_o[k].norm()) > 1e-12:
             assert rel_l2(g[k].cpu(), g_o[k]) <= 10 * tol, f"{name}: {k} {rel_l2(g[k].cpu(), g_o[k]):.3e}"
@@ -216,7 +220,8 @@ def test_arbitrary_widths(arch, pde_name, kw, engine, dev):
     pd = pde_desc_from_spec(pde)
     flat = E.new_flat_grad(prog, dev)
     r, s = E.residual_loss_grad(prog, pd, x.to(dev), t.to(dev), 1.0 / x.shape[0], flat, want_residual=True)
-    assert rel_l2(r.cpu(), r_o) <= TOL, f"{rel_l2(r.cpu(), r_o):.3e}"
+    e_r = rel_l2(r.cpu(), r_o, label="residual", tol=TOL)
+    assert e_r <= TOL, f"{e_r:.3e}"
     by_name = {n: g for n, g in zip(names, E.split_flat_grad(prog, flat)) if g is not None}
     keys = [k for k in g_o if k in by_name]
     got = torch.cat([by_name[k].flatten().cpu() for k in keys])
