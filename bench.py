@@ -149,9 +149,13 @@ def training_parity(dev, O, pspec, aspec, steps=200, batch=5000, lr=1e-3, clip=1
     bc = O.PdeSpec(name="burgers", parameters=pspec.parameters, boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}},
                    initial_condition={"type": "sine", "amplitude": -1.0, "frequency": 1.0})
 
-    def cpu_run(threads):
+    def cpu_run(threads, perturb=0.0):
         torch.set_num_threads(threads)
-        params = {k: v.clone().requires_grad_(k != "model.fourier.B") for k, v in sd0.items()}
+        params = {k: v.clone() for k, v in sd0.items()}
+        if perturb:  # theta_0 (1 + perturb * N(0, 1)), fixed seed: one rounding error's worth of difference at step 0
+            g = torch.Generator().manual_seed(9)
+            params = {k: (v * (1.0 + perturb * torch.randn(v.shape, generator=g)) if k != "model.fourier.B" else v) for k, v in params.items()}
+        params = {k: v.requires_grad_(k != "model.fourier.B") for k, v in params.items()}
         names = [k for k in params if params[k].requires_grad]
         opt = torch.optim.Adam([params[k] for k in names], lr=lr)
         out, t0 = {}, time.perf_counter()
@@ -167,6 +171,7 @@ def training_parity(dev, O, pspec, aspec, steps=200, batch=5000, lr=1e-3, clip=1
     nthr = host_threads()
     params, ref, cpu_s = cpu_run(nthr)
     _, ref1, cpu1_s = cpu_run(1)
+    _, refp, _ = cpu_run(nthr, perturb=1e-7)
     torch.set_num_threads(nthr)
 
     def drift(a):
@@ -175,7 +180,7 @@ def training_parity(dev, O, pspec, aspec, steps=200, batch=5000, lr=1e-3, clip=1
     def within(d):
         return max([int(k) for k, v in d.items() if v <= 1e-5], default=0)
 
-    d_gpu, d_det, d_cpu1 = drift(snaps), drift(snaps_det), drift(ref1)
+    d_gpu, d_det, d_cpu1, d_cpup = drift(snaps), drift(snaps_det), drift(ref1), drift(refp)
     xc, tc = xg.cpu(), tg.cpu()
     sdT = {k: v.detach() for k, v in params.items()}
     r_cpu = O.compute_residual(pspec, lambda z: O.network_forward(aspec, sdT, z), xc, tc).detach()
@@ -191,11 +196,15 @@ def training_parity(dev, O, pspec, aspec, steps=200, batch=5000, lr=1e-3, clip=1
         "u_rel_l2": float((u_gpu.cpu() - u_cpu).norm() / u_cpu.norm()),
         "theta_rel_l2_by_step": d_gpu, "steps_within_1e-5": within(d_gpu),
         "gpu_deterministic": {"theta_rel_l2_by_step": d_det, "steps_within_1e-5": within(d_det),
-                              "note": "same batches, PINNModel.set_deterministic(True): fixed-order gradient reductions"},
+                              "note": "same batches, PINNModel.set_deterministic(True): fixed-order gradient reductions (the "
+                                      "store flush of the fused kernel reduces in a fixed order in the default mode too)"},
         "cpu_control": {"theta_rel_l2_by_step": d_cpu1, "steps_within_1e-5": within(d_cpu1), "threads": [nthr, 1],
                         "cpu_seconds_1thread": cpu1_s,
                         "note": "the reference CPU path against ITSELF: same schedule, same batches, 1 thread vs all threads "
                                 "(summation order inside torch's CPU kernels) - the reference's own reproducibility envelope"},
+        "cpu_perturbed": {"theta_rel_l2_by_step": d_cpup, "steps_within_1e-5": within(d_cpup), "relative_perturbation": 1e-7,
+                          "note": "the reference CPU path against ITSELF from theta_0 (1 + 1e-7 N(0,1)): how fast this schedule amplifies "
+                                  "a difference of one fp32 rounding error (machine-independent, unlike the thread-count control)"},
         "eval_grid_points": int(xg.shape[0]), "cpu_seconds": cpu_s,
     }
 
@@ -418,8 +427,8 @@ def main():
                 "traffic_source": (traffic_src + ": rocprofv3 FETCH_SIZE (x2) + WRITE_SIZE passes of this command, committed; not "
                                    "measured inside this run") if traffic_src else None,
                 "kernel": "pinn::jet_kernel_wide<tanh, NT=1, NX=2, reverse>", "kernel_ms": kern_ms,
-                "kernel_ms_covers": "the call's launches between events on the launch stream: 1.3 MB memset of the flush rows, "
-                                    "the fused kernel, the 8-row gradient sum",
+                "kernel_ms_covers": "the call's launches between events on the launch stream: the fused kernel (every workgroup "
+                                    "stores its gradient row) and the fixed-order row sum (wide_rows_reduce)",
                 "flops_per_point": flops_pt,
             },
             "sustained": sustained,

@@ -46,10 +46,13 @@ extern "C" {
 
 /* PinnNetDesc.flags */
 #define PINN_FLAG_LAYER_NORM 1    /* feedforward: a LayerNorm follows every hidden Linear (feedforward.py:43-45) */
-#define PINN_FLAG_DETERMINISTIC 2 /* weight gradients and loss reduced in a fixed order: two launches on the same inputs
-                                     give bit-identical results (reference anchor: tests/unit_tests/test_benchmarks.py:61-64).
-                                     Both engines: per-workgroup slab rows + ordered row sum; the workspace grows by
-                                     grid x parameter count floats */
+#define PINN_FLAG_DETERMINISTIC 2 /* weight gradients (and, on calls WITH a reverse sweep, the loss sum) reduced in a fixed
+                                     order: two launches on the same inputs give bit-identical results (reference anchor:
+                                     tests/unit_tests/test_benchmarks.py:61-64).  Both engines: per-workgroup slab rows +
+                                     ordered row sum; the workspace grows by grid x parameter count floats.  Forward-only
+                                     calls: the fused tile-major kernel honours the flag for the loss sum too, the
+                                     layer-major engine accumulates it with float atomics (per-point outputs are
+                                     bit-reproducible either way) */
 #define PINN_FLAG_LAYER_MAJOR 4   /* engine hint: run the layer-major engine even where the fused tile-major kernel
                                      applies (same results to rounding; tests run both) */
 
@@ -138,7 +141,11 @@ size_t pinn_workspace_bytes(const PinnNetDesc* net, int64_t N, int32_t time_orde
 
 /* Every compute entry point: `weights` (and `weight_grads`) are tables of `num_tensors` device pointers in the
  * reference's state_dict order; the count is validated against the descriptor BEFORE any entry is read.
- * `workspace` must hold pinn_workspace_bytes(...) bytes, 16-byte aligned (may be NULL when that is 0). */
+ * `workspace` must hold pinn_workspace_bytes(...) bytes, 16-byte aligned (may be NULL when that is 0).
+ * Weight tensors: contiguous fp32, hidden-layer weight matrices 16-byte aligned where the descriptor takes the fused
+ * tile-major kernel (plain MLP family, widths multiples of 32 up to 128: it reads them in place with 16-byte loads) —
+ * a misaligned view there is refused with PINN_ERR_MISALIGNED rather than silently re-routed to the engine
+ * pinn_workspace_bytes did not size for; PINN_FLAG_LAYER_MAJOR selects the packing engine, which takes any alignment. */
 
 /* jets_out[s] : N floats each, stream order [u, d/dt.., d/dx..]; all K = 1+nt+nx entries required. */
 int pinn_jet_forward(const PinnNetDesc* net, const float* const* weights, int32_t num_tensors, const float* x,

@@ -447,15 +447,16 @@ bool fused_off() {
 bool fused_set_built(int nt, int nx) { return !(nt == 2); }  // time order 2 (wave, pendulum) stays unfused: see the Makefile
 
 // Which node kinds take the fused kernels.  Measured on MI355X (tools/micro/fused_bench.hip, tools/bench_configs.py): without
-// LayerNorm the fused launch beats GEMM + element-wise launch in both directions (C4 30.8 -> 25.5 ms); with LayerNorm the
-// forward launch wins where the consumer has no skip record, and the reverse launch — whose epilogue (two block
+// LayerNorm the fused launch beats GEMM + element-wise launch in both directions (C4 30.8 -> 26.1 ms); with LayerNorm the
+// forward launch wins (C3 25.2 -> 23.4 ms with bits 1 | 2 | 4), and the reverse launch — whose epilogue (two block
 // reductions, ~1 200 VALU instructions per wave and unit) runs with all eight waves in the same phase and nothing
-// overlapping it — only where the weight slice leaves the epilogue its registers (depth 128).  PINN_LM_FUSED_LN=<bits>
-// overrides: 1 forward, 2 forward with a skip record, 4 reverse at depth 128, 8 reverse at depth 256.
+// overlapping it — only where the weight slice leaves the epilogue its registers (depth 128; at depth 256 it spills
+// ~80 VGPRs and loses to GEMM + lm_ew_bwd_dma: 25.3 ms with all bits).  PINN_LM_FUSED_LN=<bits> overrides: 1 forward,
+// 2 forward with a skip record, 4 reverse at depth 128, 8 reverse at depth 256.
 int fused_ln_mask() {
   static const int v = [] {
     const char* e = getenv("PINN_LM_FUSED_LN");
-    return e ? atoi(e) : (1 | 4);
+    return e ? atoi(e) : (1 | 2 | 4);
   }();
   return v;
 }

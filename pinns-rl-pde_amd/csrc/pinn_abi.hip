@@ -42,6 +42,12 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+}  // namespace pinn
+
+// the training-step entry points (train_kernels.hip) leave their messages in the same thread-local string
+extern "C" int pinn_internal_fail(int code, const char* msg) { return pinn::fail(code, "%s", msg); }
+
+namespace pinn {
 
 static int num_cus() {
   static int cached = 0;
@@ -80,7 +86,7 @@ static float act_param_of(int act, float user) {
 // Wide-kernel layer program of the plain-MLP family, or false when the descriptor is outside what that kernel runs
 // (the caller then takes the layer-major engine).  `w` / `g` may be null (sizing queries); when given they hold
 // `num_tensors` entries, already validated against the descriptor.
-static bool build_wide(const PinnNetDesc* d, const float* const* w, float* const* g, NetDev* out) {
+static bool build_wide(const PinnNetDesc* d, const float* const* w, float* const* g, NetDev* out, int* misaligned = nullptr) {
   if (d->arch != PINN_ARCH_FOURIER && d->arch != PINN_ARCH_FEEDFORWARD && d->arch != PINN_ARCH_SIREN) return false;
   if (d->flags & (PINN_FLAG_LAYER_NORM | PINN_FLAG_LAYER_MAJOR)) return false;
   NetDev n;
@@ -127,7 +133,10 @@ static bool build_wide(const PinnNetDesc* d, const float* const* w, float* const
     L.out_dim = wd;
     L.act = act;
     L.act_param = par;
-    if (reinterpret_cast<uintptr_t>(L.W) & 15) return false;  // 16-byte weight loads: an odd view goes to the packed engine
+    if (reinterpret_cast<uintptr_t>(L.W) & 15) {  // 16-byte weight loads
+      if (misaligned) *misaligned = wbase + 2 * i;
+      return false;
+    }
     prev = wd;
     if (wd > hmax) hmax = wd;
   }
@@ -271,9 +280,9 @@ static hipError_t dispatch_wide(int nt, int nx, const KernelArgs& a, bool bwd, i
 }
 
 // the wide kernel runs this problem: program built, all K streams fit the LDS, engine not overridden
-static bool use_wide(const PinnNetDesc* d, const float* const* w, float* const* g, int K, bool bwd, NetDev* n) {
+static bool use_wide(const PinnNetDesc* d, const float* const* w, float* const* g, int K, bool bwd, NetDev* n, int* misaligned = nullptr) {
   if (force_lm()) return false;
-  if (!build_wide(d, w, g, n)) return false;
+  if (!build_wide(d, w, g, n, misaligned)) return false;
   return jet_wide_fits(K, n->hmax, bwd, n->n_layers);
 }
 
@@ -326,7 +335,12 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
   }
   KernelArgs a;
   memset(&a, 0, sizeof(a));
-  if (use_wide(net, weights, grads, K, bwd, &a.net)) {
+  int misaligned = -1;
+  const bool wide = use_wide(net, weights, grads, K, bwd, &a.net, &misaligned);
+  if (!wide && misaligned >= 0)  // pinn_workspace_bytes sized this descriptor for the fused kernel: say what is wrong instead of "workspace too small"
+    return fail(PINN_ERR_MISALIGNED, "weight tensor %d is not 16-byte aligned: the fused kernel of this descriptor reads hidden-layer "
+                "weights with 16-byte loads (pass aligned tensors, or set PINN_FLAG_LAYER_MAJOR to take the packing engine)", misaligned);
+  if (wide) {
     const int grid = wide_grid(a.net, K, N, bwd);
     a.pde = pd;
     a.x = x;

@@ -187,18 +187,28 @@ __global__ void step_inc_kernel(float* step) { step[0] += 1.0f; }
 
 }  // namespace
 
+extern "C" int pinn_internal_fail(int code, const char* msg);  // pinn_abi.hip: sets pinn_last_error()
+
+static int launched(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return PINN_OK;
+  char msg[256];
+  snprintf(msg, sizeof(msg), "HIP error %d: %s (%s)", (int)e, hipGetErrorString(e), what);
+  return pinn_internal_fail(PINN_ERR_HIP, msg);
+}
+
 extern "C" {
 
 int pinn_point_losses(const float* u, int32_t n_total, int32_t n_terms, const int32_t* lo, const int32_t* hi,
                       const float* const* targets, const float* weights, int32_t loss, float huber_delta,
                       float* term_losses, float* cotangent, const float* residual_sum, float residual_scale,
                       float residual_weight, int32_t n_boundary_terms, float* summary4, void* stream) {
-  if (!u || !lo || !hi || !targets || !weights || !term_losses || !cotangent) return PINN_ERR_BAD_DESC;
-  if (n_terms < 0 || n_terms > PINN_MAX_POINT_TERMS || n_total < 0) return PINN_ERR_BAD_DESC;
+  if (!u || !lo || !hi || !targets || !weights || !term_losses || !cotangent) return pinn_internal_fail(PINN_ERR_BAD_DESC, "pinn_point_losses: null argument");
+  if (n_terms < 0 || n_terms > PINN_MAX_POINT_TERMS || n_total < 0) return pinn_internal_fail(PINN_ERR_BAD_DESC, "pinn_point_losses: term count / point count out of range");
   PointTerms p;
   p.n_terms = n_terms;
   for (int k = 0; k < n_terms; ++k) {
-    if (lo[k] < 0 || hi[k] < lo[k] || hi[k] > n_total || !targets[k]) return PINN_ERR_BAD_DESC;
+    if (lo[k] < 0 || hi[k] < lo[k] || hi[k] > n_total || !targets[k]) return pinn_internal_fail(PINN_ERR_BAD_DESC, "pinn_point_losses: bad term range or null target");
     p.lo[k] = lo[k];
     p.hi[k] = hi[k];
     p.target[k] = targets[k];
@@ -208,23 +218,27 @@ int pinn_point_losses(const float* u, int32_t n_total, int32_t n_terms, const in
   p.huber_delta = huber_delta;
   hipLaunchKernelGGL(point_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), u, p, n_total, term_losses, cotangent,
                      residual_sum, residual_scale, residual_weight, n_boundary_terms, summary4);
-  return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
+  return launched("point_loss_kernel");
 }
 
 int pinn_jet_losses(const float* jets, int32_t n_streams, int32_t n_total, int32_t n_terms, const int32_t* lo, const int32_t* hi,
                     const int32_t* stream_of, const int32_t* pair_offset, const float* const* targets, const float* weights,
                     int32_t loss, float huber_delta, float* term_losses, float* cotangent, const float* residual_sum,
                     float residual_scale, float residual_weight, int32_t n_boundary_terms, float* summary4, void* stream) {
-  if (!jets || !lo || !hi || !stream_of || !pair_offset || !targets || !weights || !term_losses || !cotangent) return PINN_ERR_BAD_DESC;
-  if (n_terms < 0 || n_terms > PINN_MAX_POINT_TERMS || n_total < 0 || n_streams < 1 || n_streams > PINN_MAX_STREAMS) return PINN_ERR_BAD_DESC;
+  if (!jets || !lo || !hi || !stream_of || !pair_offset || !targets || !weights || !term_losses || !cotangent)
+    return pinn_internal_fail(PINN_ERR_BAD_DESC, "pinn_jet_losses: null argument");
+  if (n_terms < 0 || n_terms > PINN_MAX_POINT_TERMS || n_total < 0 || n_streams < 1 || n_streams > PINN_MAX_STREAMS)
+    return pinn_internal_fail(PINN_ERR_BAD_DESC, "pinn_jet_losses: term / stream / point count out of range");
   JetTerms p;
   p.n_terms = n_terms;
   for (int k = 0; k < n_terms; ++k) {
-    if (lo[k] < 0 || hi[k] < lo[k] || hi[k] > n_total || stream_of[k] < 0 || stream_of[k] >= n_streams) return PINN_ERR_BAD_DESC;
+    if (lo[k] < 0 || hi[k] < lo[k] || hi[k] > n_total || stream_of[k] < 0 || stream_of[k] >= n_streams)
+      return pinn_internal_fail(PINN_ERR_BAD_DESC, "pinn_jet_losses: bad term range or stream");
     if (pair_offset[k]) {  // the partner range must lie inside the jets and must not overlap the term's own range
-      if (pair_offset[k] < hi[k] - lo[k] || hi[k] + pair_offset[k] > n_total) return PINN_ERR_BAD_DESC;
+      if (pair_offset[k] < hi[k] - lo[k] || hi[k] + pair_offset[k] > n_total)
+        return pinn_internal_fail(PINN_ERR_BAD_DESC, "pinn_jet_losses: paired range overlaps its partner or leaves the jets");
     } else if (!targets[k]) {
-      return PINN_ERR_BAD_DESC;
+      return pinn_internal_fail(PINN_ERR_BAD_DESC, "pinn_jet_losses: null target of an unpaired term");
     }
     p.lo[k] = lo[k];
     p.hi[k] = hi[k];
@@ -237,21 +251,25 @@ int pinn_jet_losses(const float* jets, int32_t n_streams, int32_t n_total, int32
   p.huber_delta = huber_delta;
   hipLaunchKernelGGL(jet_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), jets, n_streams, p, n_total, term_losses,
                      cotangent, residual_sum, residual_scale, residual_weight, n_boundary_terms, summary4);
-  return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
+  return launched("jet_loss_kernel");
 }
 
 int pinn_adam_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
                         float beta1, float beta2, float eps, float weight_decay, float max_norm, float* step,
                         float* scratch64, float* grad_norm_out, void* stream) {
-  if (!params || !grads || !exp_avg || !exp_avg_sq || !lr || !step || !scratch64 || n <= 0) return PINN_ERR_BAD_DESC;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !lr || !step || !scratch64 || n <= 0)
+    return pinn_internal_fail(PINN_ERR_BAD_DESC, "pinn_adam_clip_step: null argument or n <= 0");
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, st, grads, (long long)n, scratch64);
+  int rc = launched("sumsq_kernel");
+  if (rc) return rc;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, (long long)n, lr, beta1,
                      beta2, eps, weight_decay, max_norm, step, scratch64, grad_norm_out);
+  if ((rc = launched("adam_kernel"))) return rc;
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
-  return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
+  return launched("step_inc_kernel");
 }
 
 }  // extern "C"

@@ -106,8 +106,15 @@ class BaseNetwork(nn.Module):
             prog = _E.NetProgram(tensors=tensors, trainable=trainable, **spec)
             prog.names = list(sd.keys())
             prog.set_deterministic(getattr(self, "_deterministic", False))
+            prog.set_layer_major(getattr(self, "_layer_major", False))
             self._prog_cache = (key, prog)
         return self._prog_cache[1]
+
+    def set_layer_major(self, on: bool = True) -> None:
+        """Engine hint (PINN_FLAG_LAYER_MAJOR), kept across rebuilds of the program like `set_deterministic`."""
+        self._layer_major = bool(on)
+        if self._prog_cache is not None:
+            self._prog_cache[1].set_layer_major(self._layer_major)
 
     def set_deterministic(self, on: bool = True) -> None:
         """Bit-reproducible weight gradients (PINN_FLAG_DETERMINISTIC: fixed-order reductions in the layer-major

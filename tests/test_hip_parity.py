@@ -378,3 +378,26 @@ def test_cpu_tensors_are_refused():
     prog, _ = program_from_spec(spec, sd, torch.device("cpu"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         E.jets_forward(prog, torch.zeros(4, 1), torch.zeros(4, 1), 1, 2)
+
+
+def test_misaligned_weight_view_is_refused_with_a_clear_error(dev):
+    """a hidden weight that is not 16-byte aligned used to be re-routed silently to the layer-major engine, whose
+    workspace the sizing call had not reported ("workspace too small").  Now: PINN_ERR_MISALIGNED naming the tensor."""
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import _lib
+    from pinnrl_amd import engine as E
+
+    spec, pde, sd, a, m = load_case("burgers_fourier_4x128")
+    prog, names = program_from_spec(spec, sd, dev)
+    k = names.index("model.layers.1.weight") if "model.layers.1.weight" in names else 3
+    w = prog.tensors[k]
+    buf = torch.zeros(w.numel() + 1, dtype=torch.float32, device=dev)
+    buf[1:].copy_(w.flatten())
+    prog.tensors[k] = buf[1:].view_as(w)  # same values, 4 bytes off a 16-byte boundary
+    assert prog.tensors[k].data_ptr() % 16 == 4
+    x, t = torch.from_numpy(a["x"]).to(dev), torch.from_numpy(a["t"]).to(dev)
+    with pytest.raises(_lib.JetLibraryError, match="16-byte aligned"):
+        E.residual_forward(prog, pde_desc_from_spec(pde), x, t)
+    prog.set_layer_major(True)  # the packing engine takes any alignment
+    r, _ = E.residual_forward(prog, pde_desc_from_spec(pde), x, t)
+    assert rel_l2(r.cpu(), a["residual64"]) <= TOL

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-N profile collection on the GPU box (one rocprofv3 run per counter group, as the pool requires):
-#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02'
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r03'
 # Output: gpurun_out/<tag>/{bench,C3,C4,C5}/{kt,pmc_*}; condense with tools/profile_summary.py.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"

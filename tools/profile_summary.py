@@ -36,7 +36,7 @@ def rows(pattern):
 
 def short(name):
     name = name.replace("void ", "").replace("pinn::lm::", "").replace("pinn::", "")
-    for tail in ("(GemmArgs)", "(GemmNtArgs)", "(EwArgs)", "(HeadArgs)", "(KernelArgs)"):
+    for tail in ("(GemmArgs)", "(GemmNtArgs)", "(EwArgs)", "(HeadArgs)", "(KernelArgs)", "(FusedArgs)"):
         name = name.replace(tail, "")
     return name[:70]
 
