@@ -1113,7 +1113,28 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
         LM_CHECK(allow_lds(kern, lds));
         const size_t stride = (size_t)g.z_rows * g.v_rows + g.z_rows;
         if (c.deterministic) g.partial = ws + L.partial;  // every element of a split's block is stored by exactly one workgroup
-        if (big && dma) hipLaunchKernelGGL(lm_gemm_nt8d, dim3(gx, gy, gz), dim3(512), lds, st, g);
+        // width-128 shapes: the LDS-DMA kernel on 256 x 128 / 128 x 256 / 128 x 128 blocks (complete blocks only)
+        static const bool ntd_on = [] { const char* e = getenv("PINN_LM_NTD"); return !(e && atoi(e) == 0); }();
+        int zr = 0, vr = 0;
+        if (ntd_on && !(big && dma) && g.z_rows % 128 == 0 && g.v_rows % 128 == 0) {
+          zr = g.z_rows % 256 == 0 ? 256 : 128;
+          vr = (g.v_rows % 256 == 0 && zr == 128) ? 256 : 128;
+        }
+        if (zr) {
+          const int gy2 = g.z_rows / zr, gz2 = g.v_rows / vr;
+          const size_t l2 = lm_gemm_ntd_lds_bytes(zr, vr);
+          int gx2 = (l2 * 2 <= 160 * 1024 ? 2 : 1) * cus / (gy2 * gz2);  // 512-thread workgroups, 64-96 KB of LDS each
+          if (gx2 > ncb / 12) gx2 = ncb / 12;
+          if (gx2 < 1) gx2 = 1;
+          if (gx2 > 512) gx2 = 512;
+          const void* k2 = zr == 256 ? reinterpret_cast<const void*>(lm_gemm_ntd<256, 128>)
+                           : (vr == 256 ? reinterpret_cast<const void*>(lm_gemm_ntd<128, 256>) : reinterpret_cast<const void*>(lm_gemm_ntd<128, 128>));
+          LM_CHECK(allow_lds(k2, l2));
+          if (zr == 256) hipLaunchKernelGGL((lm_gemm_ntd<256, 128>), dim3(gx2, gy2, gz2), dim3(512), l2, st, g);
+          else if (vr == 256) hipLaunchKernelGGL((lm_gemm_ntd<128, 256>), dim3(gx2, gy2, gz2), dim3(512), l2, st, g);
+          else hipLaunchKernelGGL((lm_gemm_ntd<128, 128>), dim3(gx2, gy2, gz2), dim3(512), l2, st, g);
+          gx = gx2;  // the deterministic reduction below sums this many partial blocks
+        } else if (big && dma) hipLaunchKernelGGL(lm_gemm_nt8d, dim3(gx, gy, gz), dim3(512), lds, st, g);
         else if (big) hipLaunchKernelGGL(lm_gemm_nt8, dim3(gx, gy, gz), dim3(512), lds, st, g);
         else hipLaunchKernelGGL(lm_gemm_nt, dim3(gx, gy, gz), dim3(kThreads), lds, st, g);
         LM_CHECK(hipGetLastError());

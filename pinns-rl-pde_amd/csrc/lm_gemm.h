@@ -784,6 +784,116 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_nt8d(const GemmNtArgs a) {  //
   if (do_db && tid < kNt8) atomicAdd(a.db + zr0 + tid, dbacc);
 }
 
+// The same kernel for blocks of width 128 (attention: dW of 512 x 128 and 128 x 512 Linears, 128 x 128 of the merged
+// value / projection; any width-128 network): ZR x VR block of dW per workgroup, ZR, VR in {128, 256}.  ZR = 256: wave w owns
+// row tile w and all VR columns (VR / 32 accumulator tiles); ZR = 128: waves = 4 row tiles x 2 column halves (VR / 64 tiles
+// each).  Round 2 ran these shapes on the register-staged kernels (lm_gemm_nt 54 %, lm_gemm_nt8 61 % MFMA busy on C5).
+template <int ZR, int VR>
+__global__ __launch_bounds__(512, 2) void lm_gemm_ntd(const GemmNtArgs a) {  // z_rows % ZR == 0 and v_rows % VR == 0
+  static_assert((ZR == 128 || ZR == 256) && (VR == 128 || VR == 256), "block shapes");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kZF = ZR * kT, kVF = VR * kT, kImg = kZF + kVF;  // floats: Z block then V block
+  constexpr int kPieces = (ZR + VR) / 8, kPpw = kPieces / 8;     // 1 KB pieces (8 rows) per stage / per wave
+  constexpr int NA = ZR == 256 ? VR / 32 : VR / 64;              // accumulator tiles per wave
+  static_assert(kPieces % 8 == 0, "a stage must divide over the eight waves");
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, ln = tid & 31, lh = (tid >> 5) & 1;
+  const int zr0 = blockIdx.y * ZR, vc0 = blockIdx.z * VR;
+  const int rtile = ZR == 256 ? wave : (wave & 3);
+  const int cbase = ZR == 256 ? 0 : (wave >> 2) * (VR / 2);  // first dW column of this wave inside the block
+  f32x16 dacc[NA];
+#pragma unroll
+  for (int kt = 0; kt < NA; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dacc[kt][r] = 0.0f;
+  float dbacc = 0.0f;
+  const bool do_db = a.db && blockIdx.z == 0;
+  const int rloc = lane >> 3, pc = lane & 7;
+  const unsigned loff = static_cast<unsigned>(rloc * kT + 4 * (pc ^ ((4 * (wave & 1) + (rloc >> 1)) & 7))) * 4u;
+  auto stage = [&](int cb, float* img) {
+    const float* zs = a.Z + ((long long)cb * a.z_rows + zr0) * kT;
+    const float* vs = a.V + ((long long)cb * a.v_rows + vc0) * kT;
+#pragma unroll
+    for (int u = 0; u < kPpw; ++u) {
+      const int p = 8 * u + wave;  // piece: 8 rows of Z (p < ZR / 8) or of V
+      const bool isz = p < ZR / 8;
+      const float* base = uniform_ptr(isz ? zs + (8 * p) * kT : vs + (8 * (p - ZR / 8)) * kT);
+      float* dst = img + p * 256;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + loff),
+                                       (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+    }
+  };
+  const int sw = (ln >> 1) & 7;
+  int buf = 0;
+  int cb = blockIdx.x;
+  if (cb < a.ncb) stage(cb, smem);
+  __syncthreads();
+  for (; cb < a.ncb; cb += gridDim.x) {
+    const int nxt = cb + gridDim.x;
+    const float* img = smem + buf * kImg;
+    if (nxt < a.ncb) stage(nxt, smem + (buf ^ 1) * kImg);
+    if (do_db && (cb % a.K) == 0 && tid < ZR) {
+      const f32x4* row = reinterpret_cast<const f32x4*>(img + tid * kT);
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 v = row[q];
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      dbacc += s;
+    }
+    {
+      const float* zrow = img + (rtile * 32 + ln) * kT;
+      const float* arow = img + kZF + (cbase + ln) * kT;
+      f32x4 zc, zn4, ac[NA], an[NA];
+      auto load_ops = [&](int g, f32x4& z, f32x4 (&av)[NA]) {
+        const int off = ((2 * g + lh) ^ sw) * 4;
+        z = *reinterpret_cast<const f32x4*>(zrow + off);
+#pragma unroll
+        for (int kt = 0; kt < NA; ++kt) av[kt] = *reinterpret_cast<const f32x4*>(arow + kt * 32 * kT + off);
+      };
+      load_ops(0, zc, ac);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g + 1 < 4) load_ops(g + 1, zn4, an);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int kt = 0; kt < NA; ++kt) dacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zc[i], ac[kt][i], dacc[kt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < 4) {
+          zc = zn4;
+#pragma unroll
+          for (int kt = 0; kt < NA; ++kt) ac[kt] = an[kt];
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  const long long row = zr0 + rtile * 32 + 4 * lh;
+  if (a.partial) {
+    float* P = a.partial + (long long)blockIdx.x * ((long long)a.z_rows * a.v_rows + a.z_rows);
+    float* base = P + row * a.v_rows + vc0 + cbase + ln;
+#pragma unroll
+    for (int kt = 0; kt < NA; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) base[(long long)((r & 3) + 8 * (r >> 2)) * a.v_rows + kt * 32] = dacc[kt][r];
+    if (do_db && tid < ZR) P[(long long)a.z_rows * a.v_rows + zr0 + tid] = dbacc;
+    return;
+  }
+  float* base = a.dW + row * a.v_rows + vc0 + cbase + ln;
+#pragma unroll
+  for (int kt = 0; kt < NA; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(base + (long long)((r & 3) + 8 * (r >> 2)) * a.v_rows + kt * 32, dacc[kt][r]);
+  if (do_db && tid < ZR) atomicAdd(a.db + zr0 + tid, dbacc);
+}
+
+inline size_t lm_gemm_ntd_lds_bytes(int zr, int vr) { return sizeof(float) * (size_t)2 * (zr + vr) * kT; }
+
 inline size_t lm_gemm_nt8d_lds_bytes() { return sizeof(float) * (size_t)2 * 2 * kNt8 * kT; }
 
 inline size_t lm_gemm_nt8_lds_bytes() { return sizeof(float) * (size_t)2 * 2 * kNt8 * kTP; }
