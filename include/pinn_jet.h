@@ -172,6 +172,17 @@ int pinn_residual_loss_grad(const PinnNetDesc* net, const float* const* weights,
                             float* residual_out, float* loss_sum_out, float* const* weight_grads, void* workspace,
                             size_t ws_bytes, void* stream);
 
+/* The same with trainable PDE coefficients (inverse problems, pinnrl/pdes/pde_base.py:246-279: get_parameter returns a live
+ * nn.Parameter that sits inside the residual): additionally coef_grads[k] += grad_scale * d(sum_n l(r_n))/d(pde->coef[k])
+ * for k = 0, 1 (device pointer to >= 2 floats, nullable = pinn_residual_loss_grad; coefficients 2 and 3 are unused by the nine
+ * PDEs).  One extra per-point reduction in the residual epilogue of the layer-major engine's head kernel; no second pass.
+ * Descriptors that would take the fused tile-major kernel must carry PINN_FLAG_LAYER_MAJOR for such a call (and for the
+ * pinn_workspace_bytes query that sizes its workspace): PINN_ERR_UNSUPPORTED otherwise. */
+int pinn_residual_loss_grad_coef(const PinnNetDesc* net, const float* const* weights, int32_t num_tensors,
+                                 const PinnPdeDesc* pde, const float* x, const float* t, int64_t N, float grad_scale,
+                                 float* residual_out, float* loss_sum_out, float* const* weight_grads, float* coef_grads,
+                                 void* workspace, size_t ws_bytes, void* stream);
+
 /* weight_grads += d(sum_n residual_cotangent[n] * r_n)/d(weights): the backward of pinn_residual_forward for an
  * arbitrary downstream graph (loss.backward() through `residual`, trainer.py:689; LRW's per-component
  * backward passes, trainer.py:607-626). */

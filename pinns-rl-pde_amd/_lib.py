@@ -29,7 +29,7 @@ LOSS = {"mse": 0, "mae": 1, "huber": 2}
 EXPORTS = (
     "pinn_abi_version", "pinn_last_error", "pinn_build_info", "pinn_num_tensors", "pinn_pde_streams",
     "pinn_workspace_bytes", "pinn_jet_forward", "pinn_jet_backward", "pinn_residual_forward", "pinn_residual_backward",
-    "pinn_residual_loss_grad", "pinn_point_losses", "pinn_jet_losses", "pinn_adam_clip_step",
+    "pinn_residual_loss_grad", "pinn_residual_loss_grad_coef", "pinn_point_losses", "pinn_jet_losses", "pinn_adam_clip_step",
 )
 
 
@@ -111,6 +111,9 @@ def load():
         lib.pinn_residual_loss_grad.restype = ctypes.c_int
         lib.pinn_residual_loss_grad.argtypes = [P(PinnNetDesc), P(vp), i32, P(PinnPdeDesc), vp, vp, i64, f32, vp, vp,
                                                 P(vp), vp, sz, vp]
+        lib.pinn_residual_loss_grad_coef.restype = ctypes.c_int
+        lib.pinn_residual_loss_grad_coef.argtypes = [P(PinnNetDesc), P(vp), i32, P(PinnPdeDesc), vp, vp, i64, f32, vp, vp,
+                                                     P(vp), vp, vp, sz, vp]
         lib.pinn_point_losses.restype = ctypes.c_int
         lib.pinn_point_losses.argtypes = [vp, i32, i32, P(i32), P(i32), P(vp), P(f32), i32, f32, vp, vp, vp, f32, f32, i32, vp, vp]
         lib.pinn_jet_losses.restype = ctypes.c_int

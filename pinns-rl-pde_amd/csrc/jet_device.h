@@ -256,6 +256,7 @@ struct PdeDev {
   int loss;
   float c0, c1, c2, c3;
   float huber_delta;
+  float* dcoef;  // reverse sweeps, nullable: dcoef[k] += sum_n rbar_n dr_n/dc_k (inverse problems: trainable coefficients)
 };
 
 template <int NT, int NX>
@@ -355,6 +356,34 @@ __device__ __forceinline__ float pde_residual(const PdeDev& p, const float* j, f
       break;
   }
   return 0.0f;
+}
+
+// dr/dc_0 and dr/dc_1 of the residual above (pde_base.py:246-279: a trainable coefficient is a live nn.Parameter inside the
+// residual; the reference gets these by autograd).  Coefficients c_2, c_3 are unused by every PDE of pinnrl/pdes/.
+template <int NT, int NX>
+__device__ __forceinline__ void pde_coef_grads(const PdeDev& p, const float* j, float x0, float& dc0, float& dc1) {
+  dc0 = dc1 = 0.0f;
+  const float u = j[0];
+  // the streams the formulas read (absent streams of a smaller compiled set: the PDE kind cannot occur with it)
+  const float ux = NX >= 1 ? j[NT + (NX >= 1 ? 1 : 0)] : 0.0f;
+  const float uxx = NX >= 2 ? j[NT + (NX >= 2 ? 2 : 0)] : 0.0f;
+  const float uxxxx = NX >= 4 ? j[NT + (NX >= 4 ? 4 : 0)] : 0.0f;
+  const int k = p.kind;
+  if (p.dimension > 1) {  // only terms that survive the reference's >= 2-D behaviour carry a coefficient
+    dc0 = k == PINN_PDE_PENDULUM ? sinf(u) : 0.0f;
+    dc1 = k == PINN_PDE_BLACK_SCHOLES ? -u : 0.0f;
+    return;
+  }
+  if (k == PINN_PDE_BURGERS || k == PINN_PDE_HEAT_LAPLACIAN) dc0 = -uxx;
+  else if (k == PINN_PDE_HEAT) dc0 = -ux;
+  else if (k == PINN_PDE_ALLEN_CAHN || k == PINN_PDE_WAVE) dc0 = -2.0f * p.c0 * uxx;
+  else if (k == PINN_PDE_CAHN_HILLIARD) dc0 = 2.0f * p.c0 * uxxxx;
+  else if (k == PINN_PDE_CONVECTION) dc0 = ux;
+  else if (k == PINN_PDE_PENDULUM) dc0 = sinf(u);
+  else if (k == PINN_PDE_BLACK_SCHOLES) {
+    dc0 = p.c0 * x0 * x0 * uxx;
+    dc1 = x0 * ux - u;
+  }
 }
 
 // l(r) and l'(r) for PDEBase._apply_loss_fn (pinnrl/pdes/pde_base.py:309-326), per sample, before the mean

@@ -1015,8 +1015,10 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       if (det) {
         SlotReduce r;
         memset(&r, 0, sizeof(r));
-        r.row = 1026;
-        r.n = 3;
+        r.row = 1028;
+        r.n = 5;
+        r.dst[3] = (c.mode == MODE_PDE) ? c.pde.dcoef : nullptr; r.slot[3] = 1026; r.mul[3] = 1; r.len[3] = 1;
+        r.dst[4] = (c.mode == MODE_PDE && c.pde.dcoef) ? c.pde.dcoef + 1 : nullptr; r.slot[4] = 1027; r.mul[4] = 1; r.len[4] = 1;
         r.dst[0] = h.dw_out; r.slot[0] = 0; r.mul[0] = 1; r.len[0] = h.H;
         r.dst[1] = (c.mode == MODE_PDE) ? c.loss_sum : nullptr; r.slot[1] = 1024; r.mul[1] = 1; r.len[1] = 1;
         r.dst[2] = h.db_out; r.slot[2] = 1025; r.mul[2] = 1; r.len[2] = 1;

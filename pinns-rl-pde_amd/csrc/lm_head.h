@@ -31,7 +31,7 @@ struct HeadArgs {
   float* U;             // [tile][K][32]
   float* dw_out;        // packed [Hp]
   float* db_out;        // packed [1]
-  float* det_partial;   // deterministic mode: per-workgroup partials [grid][1026] = dw_out (1024) | loss | db_out
+  float* det_partial;   // deterministic mode: per-workgroup partials [grid][1028] = dw_out (1024) | loss | db_out | dcoef (2)
 };
 
 template <int NT, int NX, int FPT>
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(1024) void lm_head(const HeadArgs a) {
 #pragma unroll
   for (int i = 0; i < FPT; ++i) w[i] = vec_ld(a.w_out, a.G * i, goff);  // zero on padding features
   const float b0 = a.b_out[0];
-  float ploss = 0.0f, pdb = 0.0f;
+  float ploss = 0.0f, pdb = 0.0f, pdc0 = 0.0f, pdc1 = 0.0f;
   for (long long uu = 2LL * blockIdx.x; uu < 2 * a.ntiles; uu += (uu & 1) ? 2LL * gridDim.x - 1 : 1) {
     // both 16-point halves of a tile back to back in the SAME workgroup: a 128-byte record row is then fetched from HBM
     // once (the second half hits this CU's caches) and its two 64-byte stores merge; with the halves on neighbouring
@@ -101,6 +101,12 @@ __global__ __launch_bounds__(1024) void lm_head(const HeadArgs a) {
       const float rb = !a.bwd ? 0.0f : (a.res_bar ? (ok ? a.res_bar[p] : 0.0f) : a.grad_scale * dl);
 #pragma unroll
       for (int s = 0; s < K; ++s) ub[s] = rb * d[s];
+      if (a.bwd && a.pde.dcoef && g == 0) {  // inverse problems: rbar dr/dc_k
+        float dc0, dc1;
+        pde_coef_grads<NT, NX>(a.pde, j, x0, dc0, dc1);
+        pdc0 += rb * dc0;
+        pdc1 += rb * dc1;
+      }
     }
     if (a.bwd) {
       if (g == 0) {
@@ -122,13 +128,15 @@ __global__ __launch_bounds__(1024) void lm_head(const HeadArgs a) {
   }
   __syncthreads();
   if (a.det_partial) {
-    float* P = a.det_partial + (long long)blockIdx.x * 1026;
+    float* P = a.det_partial + (long long)blockIdx.x * 1028;
     for (int i = tid; i < 1024; i += nthreads) P[i] = pacc[i];
     if (g == 0) {
-      const float ls = pt_sum(ploss), ds = pt_sum(pdb);
+      const float ls = pt_sum(ploss), ds = pt_sum(pdb), c0s = pt_sum(pdc0), c1s = pt_sum(pdc1);
       if (n == 0) {
         P[1024] = ls;
         P[1025] = ds;
+        P[1026] = c0s;
+        P[1027] = c1s;
       }
     }
     return;
@@ -140,6 +148,13 @@ __global__ __launch_bounds__(1024) void lm_head(const HeadArgs a) {
     if (n == 0) {
       if (a.mode == MODE_PDE && a.loss_sum) atomicAdd(a.loss_sum, ls);
       if (a.bwd && a.db_out) atomicAdd(a.db_out, ds);
+    }
+    if (a.bwd && a.pde.dcoef && a.mode == MODE_PDE) {
+      const float c0s = pt_sum(pdc0), c1s = pt_sum(pdc1);
+      if (n == 0) {
+        atomicAdd(a.pde.dcoef, c0s);
+        atomicAdd(a.pde.dcoef + 1, c1s);
+      }
     }
   }
 }

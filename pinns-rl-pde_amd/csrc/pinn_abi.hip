@@ -228,7 +228,7 @@ static float* det_slot(DetTable& t, float* slab, float* user, unsigned count) {
 }
 
 // all targets of a NetDev (and the loss sum) -> slab; `slab` may be null for sizing (only t.stride is then meaningful)
-static void det_redirect(NetDev& n, float*& loss_sum, float* slab, DetTable& t) {
+static void det_redirect(NetDev& n, float*& loss_sum, float*& dcoef, float* slab, DetTable& t) {
   memset(&t, 0, sizeof(t));
   static float dummy;
   float* base = slab ? slab : &dummy;
@@ -249,6 +249,7 @@ static void det_redirect(NetDev& n, float*& loss_sum, float* slab, DetTable& t) 
   slot(n.dw_out, (unsigned)n.h_last, sizing);
   slot(n.db_out, 1u, sizing);
   slot(loss_sum, 1u, sizing);
+  (void)dcoef;
   if (t.stride == 0) t.stride = 4;
 }
 
@@ -309,7 +310,8 @@ static int validate_table(const PinnNetDesc* net, const void* table, int num_ten
 static int run(const PinnNetDesc* net, const float* const* weights, float* const* grads, int num_tensors,
                const PinnPdeDesc* pde, const float* x, const float* t, int64_t N, int nt, int nx, int mode,
                float grad_scale, float* const* jets_out, const float* const* jets_bar, float* residual_out,
-               float* loss_sum, void* workspace, size_t ws_bytes, bool bwd, void* stream, const float* res_bar = nullptr) {
+               float* loss_sum, void* workspace, size_t ws_bytes, bool bwd, void* stream, const float* res_bar = nullptr,
+               float* coef_grads = nullptr) {
   int rc = validate_table(net, weights, num_tensors, "weights");
   if (rc) return rc;
   if (bwd && (rc = validate_table(net, grads, num_tensors, "weight_grads"))) return rc;
@@ -332,10 +334,18 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
     pd.c2 = pde->coef[2];
     pd.c3 = pde->coef[3];
     pd.huber_delta = pde->huber_delta;
+    pd.dcoef = bwd ? coef_grads : nullptr;
   }
   KernelArgs a;
   memset(&a, 0, sizeof(a));
   int misaligned = -1;
+  // Coefficient cotangents (inverse problems) are a reduction of the layer-major engine's head kernel only: in the fused
+  // tile-major kernel the extra per-tile code cost the headline configuration scratch (SGPR spills to memory) even with the
+  // feature off, so such calls take the layer-major engine — which the caller selects (PINN_FLAG_LAYER_MAJOR) so that
+  // pinn_workspace_bytes sizes the workspace for it.
+  if (coef_grads && !(net->flags & PINN_FLAG_LAYER_MAJOR) && !force_lm() && use_wide(net, nullptr, nullptr, K, bwd, &a.net))
+    return fail(PINN_ERR_UNSUPPORTED, "coefficient gradients run on the layer-major engine: set PINN_FLAG_LAYER_MAJOR in the "
+                "descriptor for this call and for its pinn_workspace_bytes query");
   const bool wide = use_wide(net, weights, grads, K, bwd, &a.net, &misaligned);
   if (!wide && misaligned >= 0)  // pinn_workspace_bytes sized this descriptor for the fused kernel: say what is wrong instead of "workspace too small"
     return fail(PINN_ERR_MISALIGNED, "weight tensor %d is not 16-byte aligned: the fused kernel of this descriptor reads hidden-layer "
@@ -379,7 +389,8 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
     if (det) {
       NetDev probe = a.net;
       float* lprobe = a.loss_sum;
-      det_redirect(probe, lprobe, nullptr, dt);  // sizing pass: the same stride pinn_workspace_bytes reports
+      float* cprobe = a.pde.dcoef;
+      det_redirect(probe, lprobe, cprobe, nullptr, dt);  // sizing pass: the same stride pinn_workspace_bytes reports
       need += (size_t)dt.stride * slab_rows * sizeof(float);
     }
     if (need > 0 && (!workspace || ws_bytes < need))
@@ -393,7 +404,7 @@ static int run(const PinnNetDesc* net, const float* const* weights, float* const
     if (det) {
       const unsigned stride = dt.stride;
       slab = static_cast<float*>(workspace) + tape_floats;
-      det_redirect(a.net, a.loss_sum, slab, dt);
+      det_redirect(a.net, a.loss_sum, a.pde.dcoef, slab, dt);
       dt.stride = stride;  // rows are as wide as the sizing pass said, whatever subset of targets this call has
       a.det_stride = two_level ? -(long long)stride : (long long)stride;
       a.det_mask = slab_rows - 1;
@@ -500,12 +511,14 @@ size_t pinn_workspace_bytes(const PinnNetDesc* net, int64_t N, int32_t time_orde
     if ((net->flags & PINN_FLAG_DETERMINISTIC) || (bwd && n.n_layers <= kPersist && wide_store_flush_on())) {
       DetTable dt;
       float* lprobe = nullptr;
-      det_redirect(n, lprobe, nullptr, dt);
+      float* cprobe = nullptr;
+      det_redirect(n, lprobe, cprobe, nullptr, dt);
       bytes += (size_t)dt.stride * grid * sizeof(float);
     } else if (bwd && grid > (size_t)kFlushRows) {  // the two-level flush's shared rows
       DetTable dt;
       float* lprobe = nullptr;
-      det_redirect(n, lprobe, nullptr, dt);
+      float* cprobe = nullptr;
+      det_redirect(n, lprobe, cprobe, nullptr, dt);
       bytes += (size_t)dt.stride * kFlushRows * sizeof(float);
     }
     return bytes;
@@ -550,6 +563,18 @@ int pinn_residual_loss_grad(const PinnNetDesc* net, const float* const* weights,
   if (rc) return rc;
   return run(net, weights, weight_grads, num_tensors, pde, x, t, N, nt, nx, MODE_PDE, grad_scale, nullptr, nullptr,
              residual_out, loss_sum_out, workspace, ws_bytes, true, stream);
+}
+
+int pinn_residual_loss_grad_coef(const PinnNetDesc* net, const float* const* weights, int32_t num_tensors,
+                                 const PinnPdeDesc* pde, const float* x, const float* t, int64_t N, float grad_scale,
+                                 float* residual_out, float* loss_sum_out, float* const* weight_grads, float* coef_grads,
+                                 void* workspace, size_t ws_bytes, void* stream) {
+  if (!weight_grads) return fail(PINN_ERR_BAD_DESC, "weight_grads is null");
+  int32_t nt, nx;
+  int rc = pinn_pde_streams(pde, &nt, &nx);
+  if (rc) return rc;
+  return run(net, weights, weight_grads, num_tensors, pde, x, t, N, nt, nx, MODE_PDE, grad_scale, nullptr, nullptr,
+             residual_out, loss_sum_out, workspace, ws_bytes, true, stream, nullptr, coef_grads);
 }
 
 int pinn_residual_backward(const PinnNetDesc* net, const float* const* weights, int32_t num_tensors,

@@ -266,8 +266,11 @@ def residual_forward(prog: NetProgram, pd, x: Tensor, t: Tensor, want_residual: 
 
 
 def residual_loss_grad(prog: NetProgram, pd, x: Tensor, t: Tensor, grad_scale: float, flat_grad: Tensor,
-                       want_residual: bool = False, loss_sum: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Tensor]:
-    """One launch: flat_grad += grad_scale * d(sum_n l(r_n))/d(theta); returns (residual | None, loss_sum)."""
+                       want_residual: bool = False, loss_sum: Optional[Tensor] = None,
+                       coef_grads: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Tensor]:
+    """One launch: flat_grad += grad_scale * d(sum_n l(r_n))/d(theta); returns (residual | None, loss_sum).
+    `coef_grads` (>= 2 floats on the device, accumulated): the same derivative w.r.t. the PDE coefficients pd.coef[0..1]
+    (inverse problems), from the same launch."""
     lib = _lib.load()
     dev = _require_device(x, t, flat_grad, *prog.tensors)
     x, t, N = _prep_points(prog, x, t)
@@ -275,12 +278,30 @@ def residual_loss_grad(prog: NetProgram, pd, x: Tensor, t: Tensor, grad_scale: f
     s = loss_sum if loss_sum is not None else torch.zeros(1, dtype=torch.float32, device=dev)
     if N:
         nt, nx = pde_streams(pd)
-        ws, wptr, wn = _scratch(prog, dev, N, nt, nx, True)
+        flags0 = prog.desc.flags
+        if coef_grads is not None:  # the coefficient reduction lives in the layer-major engine (sizing and call alike)
+            prog.desc.flags = flags0 | _lib.PINN_FLAG_LAYER_MAJOR
+        try:
+            ws, wptr, wn = _scratch(prog, dev, N, nt, nx, True)
+        except Exception:
+            prog.desc.flags = flags0
+            raise
         with torch.cuda.device(dev):
-            _lib.check(lib.pinn_residual_loss_grad(ctypes.byref(prog.desc), prog._weight_ptrs(), prog.num_tensors,
-                                                   ctypes.byref(pd), x.data_ptr(), t.data_ptr(), N, float(grad_scale),
-                                                   r.data_ptr() if want_residual else None, s.data_ptr(),
-                                                   _grad_ptrs(prog, flat_grad), wptr, wn, _stream(dev)))
+            if coef_grads is not None:
+                assert coef_grads.is_cuda and coef_grads.dtype == torch.float32 and coef_grads.numel() >= 2
+                try:
+                    _lib.check(lib.pinn_residual_loss_grad_coef(ctypes.byref(prog.desc), prog._weight_ptrs(), prog.num_tensors,
+                                                                ctypes.byref(pd), x.data_ptr(), t.data_ptr(), N, float(grad_scale),
+                                                                r.data_ptr() if want_residual else None, s.data_ptr(),
+                                                                _grad_ptrs(prog, flat_grad), coef_grads.data_ptr(), wptr, wn,
+                                                                _stream(dev)))
+                finally:
+                    prog.desc.flags = flags0
+            else:
+                _lib.check(lib.pinn_residual_loss_grad(ctypes.byref(prog.desc), prog._weight_ptrs(), prog.num_tensors,
+                                                       ctypes.byref(pd), x.data_ptr(), t.data_ptr(), N, float(grad_scale),
+                                                       r.data_ptr() if want_residual else None, s.data_ptr(),
+                                                       _grad_ptrs(prog, flat_grad), wptr, wn, _stream(dev)))
     return r, s
 
 
@@ -435,3 +456,30 @@ class ResidualLossFunction(torch.autograd.Function):
             return (None,) * 5 + (None,) * len(ctx.prog.tensors)
         grads = split_flat_grad(ctx.prog, ctx.flat * g)
         return (None, None, None, None, None, *grads)
+
+
+class ResidualLossCoefFunction(torch.autograd.Function):
+    """`ResidualLossFunction` for inverse problems: the PDE coefficients `coefs` (tensors in the order of PinnPdeDesc.coef,
+    some of which require grad: live `nn.Parameter`s of `PDEBase._trainable_params`, pde_base.py:246-279) are inputs of the
+    node, and their gradients come from the SAME launch as the weight gradient (fused `sum_n rbar_n dr_n/dc_k` reduction in the
+    residual epilogue) — no jets + torch epilogue, no second pass."""
+
+    @staticmethod
+    def forward(ctx, prog: NetProgram, make_pd, x: Tensor, t: Tensor, n_total: int, n_coef: int, *coefs_and_params: Tensor):
+        coefs = coefs_and_params[:n_coef]
+        pd = make_pd([float(c.detach()) for c in coefs])
+        dev = x.device
+        flat = new_flat_grad(prog, dev)
+        cg = torch.zeros(4, dtype=torch.float32, device=dev)
+        _, s = residual_loss_grad(prog, pd, x, t, 1.0 / float(n_total), flat, coef_grads=cg)
+        ctx.flat, ctx.cg, ctx.prog, ctx.n_coef = flat, cg, prog, n_coef
+        ctx.coef_meta = [(c.shape, c.dtype) for c in coefs]
+        return (s / float(n_total)).reshape(())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        grads = split_flat_grad(ctx.prog, ctx.flat * g)
+        cgs = []
+        for k, (shape, dtype) in enumerate(ctx.coef_meta):
+            cgs.append((ctx.cg[k] * g).to(dtype).reshape(shape) if k < 2 and ctx.needs_input_grad[6 + k] else None)
+        return (None, None, None, None, None, None, *cgs, *grads)

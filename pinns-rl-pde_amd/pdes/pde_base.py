@@ -543,6 +543,18 @@ class PDEBase:
     def _residual_loss(self, model, x: torch.Tensor, t: torch.Tensor, n_total: Optional[int] = None) -> torch.Tensor:
         """mean_n l(r_n): residual, reduction AND dL/dtheta in one launch when the coefficients are plain numbers."""
         if self._has_trainable_coefficients():
+            coefs = [c if isinstance(c, torch.Tensor) else torch.tensor(float(c), dtype=torch.float32, device=self.device)
+                     for c in self._coefficients()]
+            if len(coefs) <= 2 and torch.is_grad_enabled() and hasattr(model, "program") and all(c.numel() == 1 for c in coefs):
+                # fused: weight gradient AND d loss / d coefficient from the one launch (engine.ResidualLossCoefFunction)
+                self._prepare_model(model)
+                prog = model.program()
+                n = int(n_total) if n_total is not None else x.shape[0]
+                kind, dim, lname, delta = self.KIND, self.dimension, self._loss_function_name(), self._huber_delta()
+                make_pd = lambda vals: _E.pde_desc(kind, dim, vals, lname, delta)  # noqa: E731
+                coefs = [c.to(self.device) for c in coefs]
+                return _E.ResidualLossCoefFunction.apply(prog, make_pd, x.detach().to(self.device), t.detach().to(self.device), n,
+                                                         len(coefs), *coefs, *prog.tensors)
             loss = self._apply_loss_fn(self.compute_residual(model, x, t))
             if n_total is not None and int(n_total) != x.shape[0]:  # shard of a data-parallel batch: local SUM / global N
                 loss = loss * (float(x.shape[0]) / float(n_total))

@@ -95,3 +95,74 @@ def test_product_data_modes_on_the_gpu(mode, dev):
         (nu,) = list(pde.trainable_parameters_iter())
         want = float(a["inverse/dnu"])
         assert abs(float(nu.grad) - want) <= 2e-5 * abs(want), f"d total / d nu: {float(nu.grad)} vs {want}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,arch_kw,names", [
+    ("burgers", dict(architecture="fourier", hidden_dim=32, num_layers=3, mapping_size=16, scale=4.0), ["nu"]),
+    ("heat", dict(architecture="feedforward", hidden_dim=64, num_layers=3, activation="gelu"), ["alpha"]),
+    ("allen_cahn", dict(architecture="resnet", hidden_dim=32, num_layers=2, num_blocks=2), ["epsilon"]),     # layer-major engine
+    ("wave", dict(architecture="feedforward", hidden_dim=32, num_layers=3), ["c"]),
+    ("cahn_hilliard", dict(architecture="feedforward", hidden_dim=32, num_layers=3), ["epsilon"]),
+    ("black_scholes", dict(architecture="feedforward", hidden_dim=32, num_layers=3), ["sigma", "r"]),          # two coefficients
+    ("pendulum", dict(architecture="siren", hidden_dim=32, num_layers=3, omega_0=30.0), ["g", "L"]),           # c0 = g / L: chain rule
+])
+def test_fused_coefficient_gradients_match_the_oracle(kind, arch_kw, names, dev):
+    """Inverse problems: d mean l(r) / d coefficient from the residual launch itself (pinn_residual_loss_grad_coef: one fused
+    per-point reduction of rbar dr/dc_k in the epilogue of both engines) against torch autograd through the oracle with the
+    coefficient as a live tensor (what the reference does, pde_base.py:246-279); the weight gradient of the same call too."""
+    import oracle as O
+    import pinnrl_amd  # noqa: F401
+    from pinnrl_amd import pdes as P
+    from pinnrl_amd.config import Config, ModelConfig
+    from pinnrl_amd.neural_networks import PINNModel
+
+    spec = O.ArchSpec(**arch_kw)
+    defaults = {"burgers": ({"nu": 0.02}, ((-1.0, 1.0),), (0.0, 1.0)), "heat": ({"alpha": 0.05}, ((0.0, 1.0),), (0.0, 1.0)),
+                "allen_cahn": ({"epsilon": 0.05}, ((-1.0, 1.0),), (0.0, 1.0)), "wave": ({"c": 1.3}, ((0.0, 1.0),), (0.0, 1.0)),
+                "cahn_hilliard": ({"epsilon": 0.05}, ((0.0, 1.0),), (0.0, 1.0)),
+                "black_scholes": ({"sigma": 0.2, "r": 0.05}, ((0.0, 2.0),), (0.0, 1.0)),
+                "pendulum": ({"g": 9.81, "L": 1.3}, ((0.0, 1.0),), (0.0, 2.0))}
+    par, dom, tdom = defaults[kind]
+    sd = O.init_state_dict(spec, seed=81)
+    g = torch.Generator().manual_seed(82)
+    x = torch.rand(211, 1, generator=g) * (dom[0][1] - dom[0][0]) + dom[0][0]
+    t = torch.rand(211, 1, generator=g) * (tdom[1] - tdom[0]) + tdom[0]
+    # oracle, coefficients as live tensors
+    live = {k: torch.tensor(float(par[k]), requires_grad=True) for k in names}
+    pde_o = O.PdeSpec(name=kind, domain=dom, time_domain=tdom, parameters={**par, **live})
+    params = {k: v.clone().requires_grad_(not k.endswith("fourier.B")) for k, v in sd.items()}
+    pnames = [k for k in params if params[k].requires_grad]
+    # composite LayerNorm: the exact derivative (torch's fused layer_norm is wrong from the third differentiation on, DESIGN.md §2)
+    r = O.compute_residual(pde_o, lambda z: O.network_forward(spec, params, z, "composite"), x, t)
+    L = (r**2).mean()
+    want = torch.autograd.grad(L, [live[k] for k in names] + [params[k] for k in pnames], allow_unused=True)
+    want = [w if w is not None else torch.zeros_like(v) for w, v in zip(want, [live[k] for k in names] + [params[k] for k in pnames])]
+    # product
+    cfg = Config.__new__(Config)
+    cfg.device = dev
+    cfg.model = ModelConfig(input_dim=2, hidden_dim=spec.hidden_dim, output_dim=1, num_layers=spec.num_layers, activation=spec.activation,
+                            architecture=spec.architecture)
+    cfg.model.mapping_size, cfg.model.scale, cfg.model.omega_0 = spec.mapping_size, spec.scale, spec.omega_0
+    if spec.architecture == "resnet":
+        cfg.model.num_blocks = spec.num_blocks
+    model = PINNModel(cfg, device=dev)
+    model.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+    cls = {"burgers": P.BurgersEquation, "heat": P.HeatEquation, "allen_cahn": P.AllenCahnEquation, "wave": P.WaveEquation,
+           "cahn_hilliard": P.CahnHilliardEquation, "black_scholes": P.BlackScholesEquation, "pendulum": P.PendulumEquation}[kind]
+    pde = cls(P.PDEConfig(name=kind, domain=[tuple(d) for d in dom], time_domain=tdom, parameters=dict(par),
+                          boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}},
+                          initial_condition={"allen_cahn": {"type": "tanh", "epsilon": 0.1}, "cahn_hilliard": {"type": "tanh"},
+                                             "black_scholes": {"type": "call_option", "strike_price": 1.0},
+                                             "pendulum": {"type": "small_angle", "initial_angle": 0.5}}.get(kind, {"type": "sine"}),
+                          exact_solution={}, dimension=1, device=dev, trainable_parameters=list(names)))
+    loss = pde._residual_loss(model, x.to(dev), t.to(dev))
+    assert type(loss.grad_fn).__name__.startswith("ResidualLossCoefFunction"), "the fused coefficient path must be the one that runs"
+    assert abs(float(loss) - float(L)) <= 2e-5 * abs(float(L))
+    loss.backward()
+    for k, w in zip(names, want[: len(names)]):
+        got = float(pde._trainable_params[k].grad)
+        assert abs(got - float(w)) <= 2e-5 * abs(float(w)) + 1e-9, f"d loss / d {k}: {got} vs {float(w)}"
+    gt = torch.cat([p.grad.flatten().cpu() for n_, p in model.named_parameters()])
+    wt = torch.cat([w.flatten() for w in want[len(names):]])
+    assert rel_l2(gt, wt) <= 2e-5, f"{rel_l2(gt, wt):.2e}"
