@@ -461,6 +461,17 @@ int fused_ln_mask() {
   return v;
 }
 
+// Unfused GEMMs of reduction depth 384 / 512 take lm_gemm_wres16, whose weight operand is in frag16 order as well
+// (PINN_LM_WRES16=0: lm_gemm, experiments), read once.
+bool wres16_shape(int depth_p) {
+  static const bool off = [] {
+    const char* e = getenv("PINN_LM_WRES16");
+    const char* w = getenv("PINN_LM_WRES");
+    return (e && atoi(e) == 0) || (w && atoi(w) == 0);
+  }();
+  return !off && (depth_p == 384 || depth_p == 512);
+}
+
 bool fuse_shape(int rows, int depth, bool ln, Program::Fuse& f) {
   const int rp = round32(rows), dp = round32(depth);
   f.on = false;
@@ -569,9 +580,10 @@ void make_layout(const Program& P, long long N, int K, bool bwd, bool determinis
       it.off = (unsigned)off;
       it.rows = P.node[m].Hout;
       it.cols = P.node[m].Hin;
-      it.transpose = ((tr ? P.fuse_bwd[m].on : P.fuse_fwd[m].on) ? 4 : 2) + tr;  // fused kernels: 16 x 16 x 4 operand order
       it.rows_p = round32(tr ? P.node[m].Hin : P.node[m].Hout);
       it.cols_p = round32(tr ? P.node[m].Hout : P.node[m].Hin);
+      // fused kernels and lm_gemm_wres16: 16 x 16 x 4 operand order
+      it.transpose = (((tr ? P.fuse_bwd[m].on : P.fuse_fwd[m].on) || wres16_shape(it.cols_p)) ? 4 : 2) + tr;
       off += (size_t)it.rows_p * it.cols_p;
     }
   }
@@ -741,6 +753,20 @@ hipError_t launch_gemm(const GemmArgs& g0, hipStream_t st) {
     // weight-resident kernel where the wave's slice fits the register file and the double-buffered stage the LDS
     const int nch = depth >> 5;
     const int rt = out_rows > 128 ? 8 : 4;
+#define PINN_WRES16(NCH_)                                                                            \
+  if (nch == NCH_ && wres16_shape(depth)) {                                                          \
+    auto kern = lm_gemm_wres16<NCH_>;                                                                \
+    const size_t wl = lm_gemm_wres16_lds_bytes(NCH_);                                                \
+    if ((e = allow_lds(reinterpret_cast<const void*>(kern), wl)) != hipSuccess) return e;            \
+    const int gy = (out_rows + 127) / 128;                                                           \
+    int gx = num_cus() / gy;                                                                         \
+    if (gx < 1) gx = 1;                                                                              \
+    if (gx > g.ncb) gx = g.ncb;                                                                      \
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(kWresThreads), wl, st, g);                           \
+    return hipGetLastError();                                                                        \
+  }
+    PINN_WRES16(12) PINN_WRES16(16)
+#undef PINN_WRES16
 #define PINN_WRES(NCH_, RT_)                                                                         \
   if (nch == NCH_ && rt == RT_ && !gemm_wres_off()) {                                               \
     auto kern = lm_gemm_wres<NCH_, RT_>;                                                             \

@@ -27,7 +27,7 @@ constexpr int kCB = 2;     // column blocks per staged image
 constexpr int kKC = 256;   // reduction rows per staged chunk
 
 struct GemmArgs {
-  const float* W;     // packed weight (w_rows x w_cols) in MFMA fragment order (lm_common.h::frag_index)
+  const float* W;     // packed weight (w_rows x w_cols) in MFMA fragment order (lm_common.h::frag_index; lm_gemm_wres16: frag16_index)
   const float* bias;  // rows form: w_rows floats or null
   const float* X;     // input record: ncb blocks of (x_rows x 32)
   float* Y;           // output record: ncb blocks of (y_rows x 32)
@@ -433,6 +433,163 @@ __global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres(const GemmArgs a
 }
 
 inline size_t lm_gemm_wres_lds_bytes(int nch, int rt) { return sizeof(float) * (2u * (2u * (8 / rt)) * (32u * nch) * kT + 32u * rt); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-resident rows-form GEMM for reduction depths 257 .. 512 (attention's 4 H -> H Linear and its transpose on the
+// way back, width-512 networks): v_mfma_f32_16x16x4_f32, so that a wave's slice is 16 rows x depth = 128 VGPRs at depth
+// 512 (the 32 x 32 x 2 form needs 32 rows: 256).  A 512-thread workgroup owns 128 output rows (wave w: rows 16 w ..
+// 16 w + 15) and ONE column block per stage, 64 KB at depth 512, double-buffered by LDS-DMA; per k-step a lane reads the
+// two 16-point halves of reduction row 4 j + (lane >> 4) (ds_read_b32 x 2, immediate offsets; a half wave covers banks
+// 0-15 and 32-47: conflict-free without padding) and issues two MFMAs.  Weight in lm_common.h::frag16_index order.
+// lm_gemm on these shapes: 68 % MFMA busy (profiles/r03_C5.md: the weight slice re-streamed from L2 per staged image,
+// two 72 KB workgroups per CU in near-lockstep).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(kWresThreads, 1) void lm_gemm_wres16(const GemmArgs a) {
+  constexpr int DEPTH = 32 * NCH;
+  constexpr int NJ = DEPTH / 4;      // k-steps
+  constexpr int kBlk = DEPTH * kT;   // floats per column block
+  constexpr int kPpw = DEPTH / 64;   // 1 KB DMA pieces (8 reduction rows) per wave and stage
+  static_assert(NCH % 4 == 0 && NCH <= 16, "depth in 128-row steps up to 512");
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][DEPTH][32] + 128 bias values
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, kk = lane >> 4;
+  const int row0 = (int)blockIdx.y * 128 + 16 * wave;
+  const bool row_ok = row0 < a.w_rows;
+  const int y_rows = a.w_rows;
+  const int my_items = a.ncb > (int)blockIdx.x ? (a.ncb - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  if (my_items == 0) return;
+
+  float w[NJ];  // w[j] = W[row0 + (lane & 15)][4 j + (lane >> 4)]
+  {
+    const int r0 = row_ok ? row0 : 0;
+    const float* wt = a.W + (long long)((r0 >> 5) * 2 + ((r0 >> 4) & 1)) * (NJ / 4) * 256;
+#pragma unroll
+    for (int j4 = 0; j4 < NJ / 4; ++j4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wt + (j4 * 64 + lane) * 4);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) w[4 * j4 + jj] = v[jj];
+    }
+  }
+
+  // A DMA piece lands linearly (lane l at base + 16 l: 8 reduction rows x 8 chunks of 4 points); the SOURCE chunk of a lane is
+  // XOR-swizzled so that ODD rows hold their two 16-point halves swapped: ds_read_b32 banks are (address / 4) mod 32 per
+  // 32-lane half, and a half wave of a B read is rows 4 j + {0, 1} (or {2, 3}) x 16 points of one half — unswizzled, both
+  // rows on banks 0-15: every read 2-way conflicted (rocprofv3: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE).
+  const unsigned loff = static_cast<unsigned>((lane & ~7) | ((lane & 7) ^ (((lane >> 3) & 1) * 4))) * 16u;
+  auto stage = [&](int q, int buf) {  // a column block is one contiguous slab in the record and in LDS alike
+    const long long cb = (long long)blockIdx.x + (long long)q * gridDim.x;
+#pragma unroll
+    for (int u = 0; u < kPpw; ++u) {
+      const int pc = 8 * u + wave;
+      const float* base = uniform_ptr(a.X + cb * kBlk + pc * 256);
+      float* dst = smem + buf * kBlk + pc * 256;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + loff),
+                                       (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+  float* sbias = smem + 2 * kBlk;
+  if (tid < 128) {
+    const int row = (int)blockIdx.y * 128 + tid;
+    sbias[tid] = a.bias && row < a.w_rows ? a.bias[row] : 0.0f;
+  }
+  __syncthreads();  // drains vmcnt: stage 0 has landed
+
+  // accumulator register (nb, i): row row0 + 4 kk + i, point 16 nb + p
+  const unsigned voff = static_cast<unsigned>(4 * kk * kT + p) * 4u;
+  auto elem = [&](float* blk, int nb, int i) { return reinterpret_cast<float*>(reinterpret_cast<char*>(blk + i * kT + 16 * nb) + voff); };
+  f32x4 prev[2];
+  float* prev_blk = a.Y;
+  bool prev_live = false;
+  auto stage_piece = [&](int q, int buf, int u) {
+    const long long cb = (long long)blockIdx.x + (long long)q * gridDim.x;
+    const int pc = 8 * u + wave;
+    const float* base = uniform_ptr(a.X + cb * kBlk + pc * 256);
+    float* dst = smem + buf * kBlk + pc * 256;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + loff),
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+  };
+  for (int q = 0; q < my_items; ++q) {
+    const long long cb = (long long)blockIdx.x + (long long)q * gridDim.x;
+    f32x4 acc[2];
+    {
+      const bool bias_blk = a.bias && (cb % a.K) == 0;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + 16 * wave + 4 * kk);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[nb][i] = bias_blk ? b4[i] : 0.0f;
+    }
+    float* blk = uniform_ptr(a.Y + (cb * y_rows + row0) * kT);
+    const long long blk_off = blk - a.Y;
+    const bool more = q + 1 < my_items;
+    float t0[8], t1[8];
+    const float* col0 = smem + (q & 1) * kBlk + kk * kT + 16 * (kk & 1) + p;        // points p of rows 4 j + kk
+    const float* col1 = smem + (q & 1) * kBlk + kk * kT + 16 * ((kk & 1) ^ 1) + p;  // points 16 + p
+    // B operand two k-groups ahead of its MFMAs (LDS latency under the DMA's writes); the VMEM work of a stage is spread
+    // over its k-groups, one or two instructions each, so that the matrix pipe starts right after the barrier: the
+    // previous stage's tile leaves (groups 0-7), then the next stage is requested (its slot was read last in iteration
+    // q - 1, which every wave has left), then this tile's add records (needed after the last group, before any store).
+    float bq[3][4][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bq[g][i][0] = col0[(4 * g + i) * (4 * kT)];
+        bq[g][i][1] = col1[(4 * g + i) * (4 * kT)];
+      }
+#pragma unroll
+    for (int j4 = 0; j4 < NJ / 4; ++j4) {
+      if (j4 + 2 < NJ / 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bq[(j4 + 2) % 3][i][0] = col0[(4 * (j4 + 2) + i) * (4 * kT)];
+          bq[(j4 + 2) % 3][i][1] = col1[(4 * (j4 + 2) + i) * (4 * kT)];
+        }
+      }
+      if (j4 < 8) {
+        if (prev_live) *elem(prev_blk, j4 & 1, j4 >> 1) = prev[j4 & 1][j4 >> 1];  // the two 64-byte halves of a row back to back
+      } else if (j4 < 8 + kPpw) {
+        if (more) stage_piece(q + 1, (q + 1) & 1, j4 - 8);
+      } else if (j4 < 16 + kPpw) {
+        const int e = j4 - 8 - kPpw;
+        if (row_ok && a.add0) t0[e] = *elem(const_cast<float*>(a.add0) + blk_off, e >> 2, e & 3);
+        if (row_ok && a.add1) t1[e] = *elem(const_cast<float*>(a.add1) + blk_off, e >> 2, e & 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[4 * j4 + i], bq[j4 % 3][i][nb], acc[nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (row_ok) {
+      if (a.add0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e >> 2][e & 3] += t0[e];
+      }
+      if (a.add1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e >> 2][e & 3] += t1[e];
+      }
+    }
+    prev[0] = acc[0];
+    prev[1] = acc[1];
+    prev_blk = blk;
+    prev_live = row_ok;
+    __syncthreads();  // the next stage has landed (vmcnt drained); this slot is free
+  }
+  if (prev_live) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *elem(prev_blk, nb, i) = prev[nb][i];
+  }
+}
+
+inline size_t lm_gemm_wres16_lds_bytes(int nch) { return sizeof(float) * (2u * (32u * nch) * kT + 128u); }
 
 inline size_t lm_gemm_lds_bytes(int depth) { return sizeof(float) * (size_t)kCB * (depth < kKC ? depth : kKC) * kTP; }
 
