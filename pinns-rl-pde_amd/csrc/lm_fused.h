@@ -293,6 +293,11 @@ __global__ __launch_bounds__(kFThreads, 1) void lm_fused(const FusedArgs a) {
   };
   // this wave's rows of unit `it` of the landing record (reverse: the source record z; forward: the skip / add record),
   // 2 K pieces of 16 rows x 16 points, into its landing zone
+  // Landing zone: the 16 rows of a piece land with bits 0 and 2 of the row index exchanged (a per-lane SOURCE permutation; the
+  // DMA writes linearly), so that the rows 4 kk + i a half wave reads (kk in {0, 1} or {2, 3}, fixed i) sit on different halves
+  // of the 32 ds_read_b32 banks.  In row order they shared one half: every landing-zone access was 2-way conflicted
+  // (rocprofv3: SQ_LDS_BANK_CONFLICT 9-25 % of SQ_LDS_IDX_ACTIVE in the kernels with a zone).
+  const unsigned lsrc_z = static_cast<unsigned>((((lane >> 2) & 10) | (((lane >> 2) & 1) << 2) | ((lane >> 4) & 1)) * kT + (lane & 3) * 4) * 4u;
   const float* land_src = BWD ? a.Zsrc : (a.skip ? a.skip : a.add0);
   auto issue_z = [&](int it) {
     if (it >= n_iters) it = n_iters - 1;
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(kFThreads, 1) void lm_fused(const FusedArgs a) {
       for (int mb = 0; mb < 2; ++mb) {
         const float* base = uniform_ptr(zb + ((long long)s * a.rows_p + row0 + 16 * mb) * kT);
         float* dst = zl + (s * 2 + mb) * 256;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + lsrc),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + lsrc_z),
                                          (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
       }
   };
@@ -400,8 +405,10 @@ __global__ __launch_bounds__(kFThreads, 1) void lm_fused(const FusedArgs a) {
     }
 
     // ---------------------------------------------------------------- epilogue: this wave's 32 rows x 16 points x K streams
-    [[maybe_unused]] const float* zr = zl + (4 * kk) * kPT + p;  // landing zone, element (mb, ii) of stream s: zr[zoff(s, e)]
-    auto zoff = [&](int s, int e) { return ((2 * s + (e >> 2)) * 16 + (e & 3)) * kPT; };
+    // landing zone, element (mb, ii) of stream s: zr[zoff(s, e)]; row 4 kk + ii of a piece sits at position
+    // (kk & 1) + 2 (ii >> 1) + 4 (ii & 1) + 8 (kk >> 1)
+    [[maybe_unused]] const float* zr = zl + ((kk & 1) + 8 * (kk >> 1)) * kPT + p;
+    auto zoff = [&](int s, int e) { return ((2 * s + (e >> 2)) * 16 + 2 * ((e >> 1) & 1) + 4 * (e & 1)) * kPT; };
     if constexpr (LAND) wait_vm<(K * PP > 63 ? 63 : K * PP)>();  // landed: pieces issued a unit ago, >= K PP ring pieces are younger
     if constexpr (!BWD) {
       float zc[8][K];

@@ -888,7 +888,7 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_nt8d(const GemmNtArgs a) {  //
       float s = 0.0f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const f32x4 v = row[q];
+        const f32x4 v = row[q ^ ((tid >> 1) & 7)];  // any order sums the row; this one spreads a 16-lane group over all 16 slots
         s += (v[0] + v[1]) + (v[2] + v[3]);
       }
       dbacc += s;
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_ntd(const GemmNtArgs a) {  // 
       float s = 0.0f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const f32x4 v = row[q];
+        const f32x4 v = row[q ^ ((tid >> 1) & 7)];  // any order sums the row; this one spreads a 16-lane group over all 16 slots
         s += (v[0] + v[1]) + (v[2] + v[3]);
       }
       dbacc += s;
