@@ -1108,6 +1108,57 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       return PINN_OK;
     };
     if ((rc = run_ew_bwd(P.head, kMaxNodes, nullptr)) != PINN_OK) return rc;
+    // 256-multiple weight gradients are collected and run as one launch behind the sweep (lm_gemm_nt8d_batch;
+    // PINN_LM_NT_BATCH=0: one launch per layer, as the deterministic mode always does)
+    static const bool nt_batch_on = [] { const char* e = getenv("PINN_LM_NT_BATCH"); return !(e && atoi(e) == 0); }();
+    static thread_local GemmNtBatch batches[4];  // [0]: 256 x 256 blocks (nt8d); [1..3]: ntd<256,128>, <128,256>, <128,128>
+    for (GemmNtBatch& b : batches) {
+      b.n = 0;
+      b.ncb = ncb;
+      b.K = K;
+    }
+    auto flush_batch = [&](int which) -> hipError_t {
+      GemmNtBatch& batch = batches[which];
+      if (batch.n == 0) return hipSuccess;
+      const void* kern = which == 0   ? reinterpret_cast<const void*>(lm_gemm_nt8d_batch)
+                         : which == 1 ? reinterpret_cast<const void*>(lm_gemm_ntd_batch<256, 128>)
+                         : which == 2 ? reinterpret_cast<const void*>(lm_gemm_ntd_batch<128, 256>)
+                                      : reinterpret_cast<const void*>(lm_gemm_ntd_batch<128, 128>);
+      const size_t lds = which == 0 ? lm_gemm_nt8d_lds_bytes() : lm_gemm_ntd_lds_bytes(which == 1 ? 256 : 128, which == 2 ? 256 : 128);
+      hipError_t e = allow_lds(kern, lds);
+      if (e != hipSuccess) return e;
+      int gx = (lds * 2 <= 160 * 1024 ? 2 : 1) * cus / batch.n;
+      if (gx > ncb / 12) gx = ncb / 12;
+      if (gx < 1) gx = 1;
+      const dim3 grid(gx, batch.n);
+      if (which == 0) hipLaunchKernelGGL(lm_gemm_nt8d_batch, grid, dim3(512), lds, st, batch);
+      else if (which == 1) hipLaunchKernelGGL((lm_gemm_ntd_batch<256, 128>), grid, dim3(512), lds, st, batch);
+      else if (which == 2) hipLaunchKernelGGL((lm_gemm_ntd_batch<128, 256>), grid, dim3(512), lds, st, batch);
+      else hipLaunchKernelGGL((lm_gemm_ntd_batch<128, 128>), grid, dim3(512), lds, st, batch);
+      batch.n = 0;
+      return hipGetLastError();
+    };
+    auto push_jobs = [&](int which, const GemmNtArgs& g, int zr, int vr) -> hipError_t {
+      const int gy = g.z_rows / zr, gz = g.v_rows / vr;
+      GemmNtBatch& batch = batches[which];
+      if (batch.n + gy * gz > kMaxNtJobs) {
+        const hipError_t e = flush_batch(which);
+        if (e != hipSuccess) return e;
+      }
+      for (int by = 0; by < gy; ++by)
+        for (int bz = 0; bz < gz; ++bz) {
+          GemmNtBatch::Job& j = batch.job[batch.n++];
+          j.Z = g.Z;
+          j.V = g.V;
+          j.dW = g.dW;
+          j.db = bz == 0 ? g.db : nullptr;
+          j.z_rows = g.z_rows;
+          j.v_rows = g.v_rows;
+          j.zr0 = by * zr;
+          j.vc0 = bz * vr;
+        }
+      return hipSuccess;
+    };
     for (int m = P.n_nodes - 1; m >= 0; --m) {
       const Node& nd = P.node[m];
       const float* zbar = ws + L.Zbar[m];
@@ -1135,12 +1186,6 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
         if (gx > 512) gx = 512;
         static const bool dma_on = [] { const char* e = getenv("PINN_LM_NT8D"); return !(e && atoi(e) == 0); }();  // 0: register-staged nt8
         const bool dma = dma_on && big && g.z_rows % kNt8 == 0 && g.v_rows % kNt8 == 0;  // the DMA kernel takes complete blocks only
-        const size_t lds = big ? (dma ? lm_gemm_nt8d_lds_bytes() : lm_gemm_nt8_lds_bytes()) : lm_gemm_nt_lds_bytes();
-        const void* kern = big ? (dma ? reinterpret_cast<const void*>(lm_gemm_nt8d) : reinterpret_cast<const void*>(lm_gemm_nt8))
-                               : reinterpret_cast<const void*>(lm_gemm_nt);
-        LM_CHECK(allow_lds(kern, lds));
-        const size_t stride = (size_t)g.z_rows * g.v_rows + g.z_rows;
-        if (c.deterministic) g.partial = ws + L.partial;  // every element of a split's block is stored by exactly one workgroup
         // width-128 shapes: the LDS-DMA kernel on 256 x 128 / 128 x 256 / 128 x 128 blocks (complete blocks only)
         static const bool ntd_on = [] { const char* e = getenv("PINN_LM_NTD"); return !(e && atoi(e) == 0); }();
         int zr = 0, vr = 0;
@@ -1148,6 +1193,18 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
           zr = g.z_rows % 256 == 0 ? 256 : 128;
           vr = (g.v_rows % 256 == 0 && zr == 128) ? 256 : 128;
         }
+        const bool can_batch = nt_batch_on && !c.deterministic;
+        if (can_batch && dma && gy * gz <= kMaxNtJobs) {
+          LM_CHECK(push_jobs(0, g, kNt8, kNt8));
+        } else if (can_batch && zr && (g.z_rows / zr) * (g.v_rows / vr) <= kMaxNtJobs) {
+          LM_CHECK(push_jobs(zr == 256 ? 1 : (vr == 256 ? 2 : 3), g, zr, vr));
+        } else {
+        const size_t lds = big ? (dma ? lm_gemm_nt8d_lds_bytes() : lm_gemm_nt8_lds_bytes()) : lm_gemm_nt_lds_bytes();
+        const void* kern = big ? (dma ? reinterpret_cast<const void*>(lm_gemm_nt8d) : reinterpret_cast<const void*>(lm_gemm_nt8))
+                               : reinterpret_cast<const void*>(lm_gemm_nt);
+        LM_CHECK(allow_lds(kern, lds));
+        const size_t stride = (size_t)g.z_rows * g.v_rows + g.z_rows;
+        if (c.deterministic) g.partial = ws + L.partial;  // every element of a split's block is stored by exactly one workgroup
         if (zr) {
           const int gy2 = g.z_rows / zr, gz2 = g.v_rows / vr;
           const size_t l2 = lm_gemm_ntd_lds_bytes(zr, vr);
@@ -1170,6 +1227,7 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
           hipLaunchKernelGGL(lm_reduce_partials, dim3(256), dim3(256), 0, st, g.partial, (long long)stride, gx, g.dW,
                              (long long)g.z_rows * g.v_rows, g.db, g.z_rows);
           LM_CHECK(hipGetLastError());
+        }
         }
       }
       // cotangent of this node's GEMM input, then through its prologue
@@ -1231,6 +1289,7 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
       LM_CHECK(launch_gemm<false>(g, st));
       if (!pro.identity() && (rc = run_ew_bwd(pro, m, ws + L.Vbar[m])) != PINN_OK) return rc;
     }
+    for (int w = 0; w < 4; ++w) LM_CHECK(flush_batch(w));
   }
   if (c.bwd && P.n_derived > 0) {  // merged gradients back onto W_p, b_p, W_v, b_v (their packed slots), then the one unpack
     hipLaunchKernelGGL(lm_unmerge_pv_kernel, dim3(16, P.n_derived), dim3(256), 0, st, merge, params, grads);

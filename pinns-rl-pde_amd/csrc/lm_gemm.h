@@ -840,21 +840,21 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_nt8(const GemmNtArgs a) {
 // index with (row >> 1) & 7 — applied to the per-lane SOURCE address of the DMA and to the reads alike (an
 // involution; 16 consecutive rows then cover all 64 banks).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void lm_gemm_nt8d(const GemmNtArgs a) {  // z_rows and v_rows multiples of 256 only
+// One 256 x 256 block of dW (rows zr0.., columns vc0..) accumulated over the column blocks split, split + nsplits, ...
+__device__ __forceinline__ void nt8d_block(const GemmNtArgs& a, const int zr0, const int vc0, const bool do_db, const int split,
+                                           const int nsplits) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kBlkF = kNt8 * kT;      // floats per staged block (256 rows x 32 points)
   constexpr int kImg = 2 * kBlkF;       // Z block then V block
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, ln = tid & 31, lh = (tid >> 5) & 1;
-  const int zr0 = blockIdx.y * kNt8, vc0 = blockIdx.z * kNt8;
   f32x16 dacc[8];
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dacc[kt][r] = 0.0f;
   float dbacc = 0.0f;
-  const bool do_db = a.db && blockIdx.z == 0;
 
   // DMA piece p = 8 u + wave (u = 0..7): pieces 0..31 are 8-row groups of Z, 32..63 of V; lane l -> row 8 p' + (l >> 3),
   // physical chunk l & 7 = logical chunk ^ ((row >> 1) & 7).  (row >> 1) & 7 depends on the piece only through its
@@ -876,11 +876,11 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_nt8d(const GemmNtArgs a) {  //
 
   const int sw = (ln >> 1) & 7;  // read-side swizzle of this lane's rows (Z row wave * 32 + ln, V rows kt * 32 + ln)
   int buf = 0;
-  int cb = blockIdx.x;
+  int cb = split;
   if (cb < a.ncb) stage(cb, smem);
   __syncthreads();
-  for (; cb < a.ncb; cb += gridDim.x) {
-    const int nxt = cb + gridDim.x;
+  for (; cb < a.ncb; cb += nsplits) {
+    const int nxt = cb + nsplits;
     const float* img = smem + buf * kImg;
     if (nxt < a.ncb) stage(nxt, smem + (buf ^ 1) * kImg);  // lands under the MFMAs below
     if (do_db && (cb % a.K) == 0 && tid < kNt8) {
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_nt8d(const GemmNtArgs a) {  //
     buf ^= 1;
   }
   if (a.partial) {
-    float* P = a.partial + (long long)blockIdx.x * ((long long)a.z_rows * a.v_rows + a.z_rows);
+    float* P = a.partial + (long long)split * ((long long)a.z_rows * a.v_rows + a.z_rows);
     float* base = P + (long long)(zr0 + wave * 32 + 4 * lh) * a.v_rows + vc0 + ln;
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
@@ -941,12 +941,50 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_nt8d(const GemmNtArgs a) {  //
   if (do_db && tid < kNt8) atomicAdd(a.db + zr0 + tid, dbacc);
 }
 
+
+__global__ __launch_bounds__(512, 2) void lm_gemm_nt8d(const GemmNtArgs a) {  // z_rows and v_rows multiples of 256 only
+  nt8d_block(a, blockIdx.y * kNt8, blockIdx.z * kNt8, a.db && blockIdx.z == 0, blockIdx.x, gridDim.x);
+}
+
+// All 256-multiple weight gradients of a reverse sweep in ONE launch, after the sweep (every Zbar / V record of the chunk is
+// still in the workspace): grid (splits, jobs), a job = one 256 x 256 block of one layer's dW.  What it saves is the
+// flush: a workgroup's 256 KB block goes out as 65 536 float atomics, 64 MB per launch chip-wide, 41 of the 449 us of a
+// per-layer launch on C3 (rocprofv3, kernel without its flush) — paid once per chunk instead of once per layer — and the
+// per-launch ramp.
+constexpr int kMaxNtJobs = 48;
+struct GemmNtBatch {
+  int n, ncb, K;
+  struct Job {
+    const float* Z;
+    const float* V;
+    float* dW;
+    float* db;  // null unless this block owns the bias gradient of its rows
+    int z_rows, v_rows, zr0, vc0;
+  } job[kMaxNtJobs];
+};
+
+__global__ __launch_bounds__(512, 2) void lm_gemm_nt8d_batch(const GemmNtBatch b) {
+  const GemmNtBatch::Job& j = b.job[blockIdx.y];
+  GemmNtArgs a;
+  a.Z = j.Z;
+  a.V = j.V;
+  a.dW = j.dW;
+  a.db = j.db;
+  a.partial = nullptr;
+  a.z_rows = j.z_rows;
+  a.v_rows = j.v_rows;
+  a.ncb = b.ncb;
+  a.K = b.K;
+  nt8d_block(a, j.zr0, j.vc0, j.db != nullptr, blockIdx.x, gridDim.x);
+}
+
 // The same kernel for blocks of width 128 (attention: dW of 512 x 128 and 128 x 512 Linears, 128 x 128 of the merged
 // value / projection; any width-128 network): ZR x VR block of dW per workgroup, ZR, VR in {128, 256}.  ZR = 256: wave w owns
 // row tile w and all VR columns (VR / 32 accumulator tiles); ZR = 128: waves = 4 row tiles x 2 column halves (VR / 64 tiles
 // each).  Round 2 ran these shapes on the register-staged kernels (lm_gemm_nt 54 %, lm_gemm_nt8 61 % MFMA busy on C5).
 template <int ZR, int VR>
-__global__ __launch_bounds__(512, 2) void lm_gemm_ntd(const GemmNtArgs a) {  // z_rows % ZR == 0 and v_rows % VR == 0
+__device__ __forceinline__ void ntd_block(const GemmNtArgs& a, const int zr0, const int vc0, const bool do_db, const int split,
+                                          const int nsplits) {  // z_rows % ZR == 0 and v_rows % VR == 0
   static_assert((ZR == 128 || ZR == 256) && (VR == 128 || VR == 256), "block shapes");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kZF = ZR * kT, kVF = VR * kT, kImg = kZF + kVF;  // floats: Z block then V block
@@ -956,7 +994,6 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_ntd(const GemmNtArgs a) {  // 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, ln = tid & 31, lh = (tid >> 5) & 1;
-  const int zr0 = blockIdx.y * ZR, vc0 = blockIdx.z * VR;
   const int rtile = ZR == 256 ? wave : (wave & 3);
   const int cbase = ZR == 256 ? 0 : (wave >> 2) * (VR / 2);  // first dW column of this wave inside the block
   f32x16 dacc[NA];
@@ -965,7 +1002,6 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_ntd(const GemmNtArgs a) {  // 
 #pragma unroll
     for (int r = 0; r < 16; ++r) dacc[kt][r] = 0.0f;
   float dbacc = 0.0f;
-  const bool do_db = a.db && blockIdx.z == 0;
   const int rloc = lane >> 3, pc = lane & 7;
   const unsigned loff = static_cast<unsigned>(rloc * kT + 4 * (pc ^ ((4 * (wave & 1) + (rloc >> 1)) & 7))) * 4u;
   auto stage = [&](int cb, float* img) {
@@ -983,11 +1019,11 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_ntd(const GemmNtArgs a) {  // 
   };
   const int sw = (ln >> 1) & 7;
   int buf = 0;
-  int cb = blockIdx.x;
+  int cb = split;
   if (cb < a.ncb) stage(cb, smem);
   __syncthreads();
-  for (; cb < a.ncb; cb += gridDim.x) {
-    const int nxt = cb + gridDim.x;
+  for (; cb < a.ncb; cb += nsplits) {
+    const int nxt = cb + nsplits;
     const float* img = smem + buf * kImg;
     if (nxt < a.ncb) stage(nxt, smem + (buf ^ 1) * kImg);
     if (do_db && (cb % a.K) == 0 && tid < ZR) {
@@ -1032,7 +1068,7 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_ntd(const GemmNtArgs a) {  // 
   }
   const long long row = zr0 + rtile * 32 + 4 * lh;
   if (a.partial) {
-    float* P = a.partial + (long long)blockIdx.x * ((long long)a.z_rows * a.v_rows + a.z_rows);
+    float* P = a.partial + (long long)split * ((long long)a.z_rows * a.v_rows + a.z_rows);
     float* base = P + row * a.v_rows + vc0 + cbase + ln;
 #pragma unroll
     for (int kt = 0; kt < NA; ++kt)
@@ -1047,6 +1083,28 @@ __global__ __launch_bounds__(512, 2) void lm_gemm_ntd(const GemmNtArgs a) {  // 
 #pragma unroll
     for (int r = 0; r < 16; ++r) atomicAdd(base + (long long)((r & 3) + 8 * (r >> 2)) * a.v_rows + kt * 32, dacc[kt][r]);
   if (do_db && tid < ZR) atomicAdd(a.db + zr0 + tid, dbacc);
+}
+
+template <int ZR, int VR>
+__global__ __launch_bounds__(512, 2) void lm_gemm_ntd(const GemmNtArgs a) {
+  ntd_block<ZR, VR>(a, blockIdx.y * ZR, blockIdx.z * VR, a.db && blockIdx.z == 0, blockIdx.x, gridDim.x);
+}
+
+// every ZR x VR block of a reverse sweep's weight gradients in one launch (see lm_gemm_nt8d_batch): grid (splits, jobs)
+template <int ZR, int VR>
+__global__ __launch_bounds__(512, 2) void lm_gemm_ntd_batch(const GemmNtBatch b) {
+  const GemmNtBatch::Job& j = b.job[blockIdx.y];
+  GemmNtArgs a;
+  a.Z = j.Z;
+  a.V = j.V;
+  a.dW = j.dW;
+  a.db = j.db;
+  a.partial = nullptr;
+  a.z_rows = j.z_rows;
+  a.v_rows = j.v_rows;
+  a.ncb = b.ncb;
+  a.K = b.K;
+  ntd_block<ZR, VR>(a, j.zr0, j.vc0, j.db != nullptr, blockIdx.x, gridDim.x);
 }
 
 inline size_t lm_gemm_ntd_lds_bytes(int zr, int vr) { return sizeof(float) * (size_t)2 * (zr + vr) * kT; }
