@@ -950,7 +950,8 @@ int lm_run(const CallArgs& c, char* err, size_t en) {
     auto fused_grid = [&](const Program::Fuse& f) {
       long long g = cus / f.gy;
       if (g < 1) g = 1;
-      return (int)(g < ct ? g : ct);
+      const long long work = f.rt == 8 ? 2 * ct : ct;  // 16-point units / whole tiles (lm_fused.h)
+      return (int)(g < work ? g : work);
     };
     for (int m = 0; m < P.n_nodes; ++m) {
       const Node& nd = P.node[m];

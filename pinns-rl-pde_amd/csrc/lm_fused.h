@@ -237,8 +237,16 @@ __global__ __launch_bounds__(kFThreads, 1) void lm_fused(const FusedArgs a) {
   const int p = lane & 15, kk = lane >> 4;
   const int blk_row0 = (int)blockIdx.y * (32 * RT);
   const int row0 = blk_row0 + 32 * rt;  // first output row of this wave
-  const long long my_tiles = a.ntiles > (long long)blockIdx.x ? (a.ntiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-  const int n_iters = (int)(CG == 1 ? 2 * my_tiles : my_tiles);
+  // Work items: whole tiles for two wave groups (one half each), dealt round-robin; 16-point units for one, dealt as
+  // CONTIGUOUS runs (a launch of 3 125 tiles on 256 CUs is 12.2 tiles each: as tiles the slowest workgroup takes 13, as
+  // units 12.5; contiguous, so that the two halves of a tile — the two 64-byte halves of every 128-byte line of its
+  // records — are read by the same workgroup back to back: dealt round-robin they went to two workgroups at the same
+  // moment, every line was fetched twice, and the HBM-bound attention launches lost 2 %).
+  const long long n_work = CG == 1 ? 2 * a.ntiles : a.ntiles;
+  const long long w_q = n_work / gridDim.x, w_r = n_work % gridDim.x;
+  const long long w_start = CG == 1 ? (long long)blockIdx.x * w_q + ((long long)blockIdx.x < w_r ? blockIdx.x : w_r) : blockIdx.x;
+  const int n_iters = CG == 1 ? (int)(w_q + ((long long)blockIdx.x < w_r ? 1 : 0))
+                              : (int)(n_work > (long long)blockIdx.x ? (n_work - 1 - blockIdx.x) / gridDim.x + 1 : 0);
   if (n_iters == 0) return;
   float* red = redb + cg * (2 * 8 * kRedQ * kPT);
   float* pacc = paccb + cg * 512;  // the two groups of RT = 4 own the same features (of different half tiles)
@@ -273,8 +281,9 @@ __global__ __launch_bounds__(kFThreads, 1) void lm_fused(const FusedArgs a) {
   };
   load_w();
 
-  auto tile_of = [&](int it) -> long long { return (long long)blockIdx.x + (long long)(CG == 1 ? it >> 1 : it) * gridDim.x; };
-  auto half_of = [&](int it, int g) -> int { return CG == 1 ? (it & 1) : g; };
+  auto work_of = [&](int it) -> long long { return CG == 1 ? w_start + it : w_start + (long long)it * gridDim.x; };
+  auto tile_of = [&](int it) -> long long { return CG == 1 ? work_of(it) >> 1 : work_of(it); };
+  auto half_of = [&](int it, int g) -> int { return CG == 1 ? (int)(work_of(it) & 1) : g; };
 
   // DMA of stage (it, s) into ring slot `buf`: piece pc = 8 u + wave covers 16 reduction rows of wave group pc / (DEPTH / 16)
   const unsigned lsrc = static_cast<unsigned>((lane >> 2) * kT + (lane & 3) * 4) * 4u;

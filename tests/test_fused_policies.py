@@ -2,7 +2,8 @@
 and the fused GEMM + prologue kernels (lm_fused.h); which nodes take which is a measured policy read ONCE per process
 (PINN_LM_FUSED, PINN_LM_FUSED_LN, lm_engine.hip::plan_fusion).  The default policy runs in every other GPU test; here
 the full-depth / full-width parity tests run again in child processes with everything unfused and with every
-LayerNorm node fused (kernels the default policy leaves to the unfused path must stay correct: they are selectable)."""
+LayerNorm node fused (kernels the default policy leaves to the unfused path must stay correct: they are selectable),
+and with the two GEMM-side choices of lm_engine.hip switched back (PINN_LM_WRES16, PINN_LM_NT_BATCH)."""
 import os
 import subprocess
 import sys
@@ -13,8 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"PINN_LM_FUSED": "0"}, {"PINN_LM_FUSED_LN": "15"}, {"PINN_LM_FUSED_LN": "0"}],
-                         ids=["unfused", "all-layernorm-nodes-fused", "no-layernorm-node-fused"])
+@pytest.mark.parametrize("env", [{"PINN_LM_FUSED": "0"}, {"PINN_LM_FUSED_LN": "15"}, {"PINN_LM_FUSED_LN": "0"},
+                                 {"PINN_LM_WRES16": "0", "PINN_LM_NT_BATCH": "0"}],
+                         ids=["unfused", "all-layernorm-nodes-fused", "no-layernorm-node-fused",
+                              "depth-512-gemm-streamed-and-one-dw-launch-per-layer"])
 def test_width256_parity_under_policy(env):
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_width256_parity.py", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"],

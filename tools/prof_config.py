@@ -19,8 +19,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("tag")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--forward", action="store_true")
+ap.add_argument("--points", type=int, default=0, help="override the configuration's point count (fixed-cost fits)")
 args = ap.parse_args()
 name, net, eq, n_req = B.CONFIGS[args.tag]()
+if args.points:
+    n_req = args.points
 dev = B.dev
 torch.manual_seed(1)
 if args.tag == "C3":
