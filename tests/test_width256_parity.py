@@ -186,6 +186,7 @@ def test_baseline_networks_full_depth_gradient(name, arch, pde_name, dim, kw, de
     ("feedforward", "burgers", dict(hidden_dims=[50, 70, 33], activation="gelu")),       # nothing a multiple of 32
     ("feedforward", "burgers", dict(hidden_dim=512, num_layers=2, activation="tanh")),   # config.yaml:16,27
     ("resnet", "allen_cahn", dict(hidden_dim=512, num_layers=1, num_blocks=1, activation="tanh")),
+    ("feedforward", "burgers", dict(hidden_dim=384, num_layers=2, activation="tanh")),   # depth 384: lm_gemm_wres16<12>
     ("feedforward", "kdv", dict(hidden_dim=124, num_layers=3, activation="tanh", layer_norm=True)),  # YAML default shape
     ("siren", "kdv", dict(hidden_dims=[124, 124], omega_0=6.0)),
     # LayerNorm widths between the tested 128 and 256: 6 / 10 / 13 waves per workgroup in the element-wise kernels and
@@ -257,3 +258,51 @@ def test_deterministic_mode_at_width_256(dev):
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
     assert rel_l2(runs[0][0].cpu(), ref.cpu()) <= TOL
     assert abs(float(runs[0][1]) - float(s_ref)) <= TOL * abs(float(s_ref))
+
+
+@pytest.mark.parametrize("arch,pde_name,kw", [
+    ("attention", "burgers", dict(hidden_dim=128, num_layers=1, num_heads=4, activation="gelu")),   # depth-512 GEMMs, 128-wide dW blocks
+    ("attention", "allen_cahn", dict(hidden_dim=96, num_layers=1, num_heads=4, activation="gelu")), # depth 384
+    ("siren", "kdv", dict(hidden_dim=512, num_layers=2, omega_0=6.0)),                              # depth 512 x 512 rows
+    ("resnet", "allen_cahn", dict(hidden_dim=256, num_layers=1, num_blocks=1, activation="tanh")),  # 256 x 256 dW blocks, batched
+], ids=["attention128", "attention96", "siren512", "resnet256"])
+def test_steady_state_of_the_persistent_gemm_loops(arch, pde_name, kw, dev):
+    """The persistent GEMM kernels (lm_gemm_wres16 / lm_gemm_wres, lm_fused, the batched dW launches) double-buffer their
+    staged blocks and hand finished tiles over to the next loop iteration; at the fixture sizes every workgroup gets ONE
+    block, so that hand-over never runs.  Here one launch over 40 000 points (up to 20 blocks per workgroup) must equal
+    the sum of 20 launches over 2 000-point slices (at most one block per workgroup): per-point residuals bit for bit
+    — they do not depend on which workgroup or loop iteration computes them —, loss and gradient to rounding; and the
+    residuals of a sample of points must match the fp64 oracle."""
+    import oracle as O
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import engine as E
+
+    spec = O.ArchSpec(architecture=arch, **kw)
+    params = {"burgers": {"nu": 0.02}, "kdv": {}, "allen_cahn": {"epsilon": 0.05}}[pde_name]
+    domain = ((-3.0, 3.0),) if pde_name == "kdv" else ((-1.0, 1.0),)
+    pde = O.PdeSpec(name=pde_name, domain=domain, parameters=params)
+    sd = O.init_state_dict(spec, seed=81)
+    torch.manual_seed(82)
+    N, S = 40000, 2000
+    x = ((torch.rand(N, 1) * 2 - 1) * domain[0][1]).to(dev)
+    t = torch.rand(N, 1).to(dev)
+    prog, names = program_from_spec(spec, sd, dev)
+    prog.set_layer_major(True)
+    pd = pde_desc_from_spec(pde)
+    flat = E.new_flat_grad(prog, dev)
+    r, s = E.residual_loss_grad(prog, pd, x, t, 1.0 / N, flat, want_residual=True)
+    parts, fsum, ssum = [], E.new_flat_grad(prog, dev), 0.0
+    for lo in range(0, N, S):
+        rp, sp = E.residual_loss_grad(prog, pd, x[lo:lo + S].contiguous(), t[lo:lo + S].contiguous(), 1.0 / N, fsum, want_residual=True)
+        parts.append(rp)
+        ssum += float(sp)
+    assert torch.equal(torch.cat(parts), r), "per-point residuals differ between one launch and per-slice launches"
+    assert abs(float(s) - ssum) <= 2e-5 * abs(ssum)
+    e_g = rel_l2(flat.cpu(), fsum.cpu(), label="gradient, one launch vs slices", tol=2e-5)
+    assert e_g <= 2e-5, f"{e_g:.3e}"
+    idx = torch.linspace(0, N - 1, 300).long()
+    sd64 = {k: v.double() for k, v in sd.items()}
+    r_o = O.compute_residual(pde, lambda inp: O.network_forward(spec, sd64, inp, "composite"), x[idx.to(dev)].cpu().double(),
+                             t[idx.to(dev)].cpu().double()).detach()
+    e_r = rel_l2(r[idx.to(dev)].cpu(), r_o, label="residual sample", tol=TOL)
+    assert e_r <= TOL, f"{e_r:.3e}"
