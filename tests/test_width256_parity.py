@@ -156,6 +156,9 @@ def _full(arch, pde_name, dim=1, n=256, **kw):
     ("C4 kdv / siren 8x256", "siren", "kdv", 1, dict(hidden_dim=256, num_layers=8, omega_0=30.0)),
     ("C5 cahn-hilliard 2-D / attention 4x128", "attention", "cahn_hilliard", 2,
      dict(hidden_dim=128, num_layers=4, activation="gelu", num_heads=4)),
+    # first Linear behind three / two input columns at width 256 (its adjoint: lm_ew_bwd's per-feature sums)
+    ("2-D input / feedforward 3x256", "feedforward", "cahn_hilliard", 2, dict(hidden_dim=256, num_layers=3, activation="tanh")),
+    ("1-D input / feedforward gelu 3x256", "feedforward", "burgers", 1, dict(hidden_dim=256, num_layers=3, activation="gelu")),
 ])
 def test_baseline_networks_full_depth_gradient(name, arch, pde_name, dim, kw, dev):
     """the weight gradient of the five BASELINE networks at their full depth and width, through the
