@@ -190,6 +190,8 @@ def test_baseline_networks_full_depth_gradient(name, arch, pde_name, dim, kw, de
     ("feedforward", "burgers", dict(hidden_dim=512, num_layers=2, activation="tanh")),   # config.yaml:16,27
     ("resnet", "allen_cahn", dict(hidden_dim=512, num_layers=1, num_blocks=1, activation="tanh")),
     ("feedforward", "burgers", dict(hidden_dim=384, num_layers=2, activation="tanh")),   # depth 384: lm_gemm_wres16<12>
+    # 13 Linears of 512 x 512 = 52 blocks of 256 x 256: more than one batched weight-gradient launch holds (48 jobs)
+    ("feedforward", "burgers", dict(hidden_dim=512, num_layers=14, activation="tanh")),
     ("feedforward", "kdv", dict(hidden_dim=124, num_layers=3, activation="tanh", layer_norm=True)),  # YAML default shape
     ("siren", "kdv", dict(hidden_dims=[124, 124], omega_0=6.0)),
     # LayerNorm widths between the tested 128 and 256: 6 / 10 / 13 waves per workgroup in the element-wise kernels and
