@@ -254,6 +254,54 @@ def secondary_configs(E):
     return out
 
 
+def sharded_configs(E, D, dist, dev, rank, world):
+    """N > 1 only.  BASELINE configs[3] (KdV, siren 8x256, 200k points, "4xMI355X data-parallel") and configs[4]
+    (Cahn-Hilliard 2-D, attention, 1M points "sharded 8xMI355X with RCCL loss all-reduce") in their multi-GPU form: ONE
+    global batch (identical on every rank under a seed), contiguous row shards (distributed.shard_bounds), the local
+    residual sum scaled by the GLOBAL 1/N, one in-place all-reduce of the flat gradient per step.  Max over ranks."""
+    import bench_configs as B
+
+    B.dev = dev
+    out = {}
+    for tag in ("C4", "C5"):
+        name, net, eq, n_req = B.CONFIGS[tag]()  # theta_0 under a fixed seed: identical replicas
+        torch.manual_seed(11)
+        x, t = eq.generate_collocation_points(n_req, strategy="uniform")
+        N = x.shape[0]
+        lo, hi = D.shard_bounds(N, rank, world)
+        xs, ts_ = x[lo:hi].contiguous(), t[lo:hi].contiguous()
+        del x, t
+        prog, pd = net.program(), eq._pde_desc()
+        flat = E.new_flat_grad(prog, dev)
+        for _ in range(2):
+            flat.zero_()
+            E.residual_loss_grad(prog, pd, xs, ts_, 1.0 / N, flat)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        dist.barrier()
+        steps = 5
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            flat.zero_()
+            E.residual_loss_grad(prog, pd, xs, ts_, 1.0 / N, flat)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        ms = torch.tensor([1e3 * (time.perf_counter() - t0) / steps], dtype=torch.float64, device=dev)
+        dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        nt, nx = E.pde_streams(pd)
+        K = 1 + nt + nx
+        tf = 3 * K * prog.flops_per_point() * N / (float(ms) * 1e-3) / 1e12
+        out[tag] = {"workload": name, "global_points": int(N), "points_per_gpu": int(hi - lo), "n_gpus": world, "streams": K,
+                    "ms_per_step": float(ms), "points_per_s": N / float(ms) * 1e3, "tflops_aggregate": tf,
+                    "frac_of_n_gpu_peak": tf / (PEAK_F32_MFMA_TFLOPS * world),
+                    "collective": f"1 all-reduce/step of the flat gradient ({flat.numel()} floats)",
+                    "baseline_config": "configs[3]: 4xMI355X data-parallel" if tag == "C4" else "configs[4]: sharded 8xMI355X, loss all-reduce"}
+        del net, eq, xs, ts_, flat, prog
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -393,6 +441,10 @@ def main():
                                                "max over ranks, vs the same batch on rank 0 alone"}
         del xs, ts_
 
+    sharded = None
+    if world > 1 and not args.no_secondary:
+        sharded = sharded_configs(E, D, dist, dev, rank, world)
+
     if rank == 0:
         K = 4
         flops_pt = 3 * K * prog.flops_per_point()  # forward jets + delta-propagation + weight-gradient GEMMs
@@ -433,6 +485,7 @@ def main():
             },
             "sustained": sustained,
             "strong": strong_fig,
+            "sharded": sharded,
             "residual_l2_theta0": math.sqrt(float(loss_sum) / n_global),
             "build_info": _lib.build_info() or "all kernel units in their preferred form",
         }

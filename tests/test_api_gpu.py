@@ -423,6 +423,12 @@ def test_bench_multi_rank_rehearsal(scaling, dev):
     assert out["config"]["global_points"] == (n if scaling == "strong" else 2 * n)
     assert out["config"]["points_per_gpu"] == (n - n // 2 if scaling == "strong" else n)
     assert "all-reduce" in out["config"]["collective"]
+    # BASELINE configs[3] / configs[4] in their multi-GPU form: one global batch, row shards, one all-reduce per step
+    sh = out["sharded"]
+    assert set(sh) == {"C4", "C5"}
+    assert sh["C4"]["global_points"] == 199809 and sh["C5"]["global_points"] == 1000000
+    for v in sh.values():
+        assert v["n_gpus"] == 2 and v["ms_per_step"] > 0 and 0 < v["points_per_gpu"] <= v["global_points"] // 2 + 1
 
 
 def test_rar_probabilities_match_the_oracle(dev):
