@@ -399,12 +399,18 @@ __device__ __forceinline__ void load_source(const EwArgs& a, long long rec_off, 
   }
 }
 
+// Lanes beyond the batch (the ragged end of the last tile) take the LAST point's coordinates, not zeros: their cotangents
+// are zero (lm_head.h seeds nothing for them), so they contribute 0 x finite to every reduction.  With zero coordinates and
+// a zero-initialised first bias every feature of such a lane is equal, a LayerNorm there divides by sqrt(eps), its 4th-order
+// jets reach 1e20 after a few layers, overflow fp32, and 0 x inf = NaN went into every weight gradient
+// (tools/fuzz_parity.py: attention x Cahn-Hilliard 1-D, two layers, any width).
 __device__ __forceinline__ void load_coords(const EwArgs& a, long long unit, int n, float (&xin)[4], bool& ok) {
-  const long long p = a.p_base + unit * kPT + n;
+  long long p = a.p_base + unit * kPT + n;
   ok = p < a.N;
+  p = ok ? p : a.N - 1;
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) xin[cc] = 0.0f;
-  if (a.src_kind != SRC_REC && ok) {
+  if (a.src_kind != SRC_REC) {
     const float* xs = in_loop(a.x);
     const float* ts = in_loop(a.t);
 #pragma unroll

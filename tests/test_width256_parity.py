@@ -311,3 +311,42 @@ def test_steady_state_of_the_persistent_gemm_loops(arch, pde_name, kw, dev):
                              t[idx.to(dev)].cpu().double()).detach()
     e_r = rel_l2(r[idx.to(dev)].cpu(), r_o, label="residual sample", tol=TOL)
     assert e_r <= TOL, f"{e_r:.3e}"
+
+
+@pytest.mark.parametrize("arch,pde_name,kw,n,tol", [
+    ("attention", "cahn_hilliard", dict(hidden_dim=32, num_layers=2, num_heads=4, activation="gelu"), 33, TOL),
+    # one of these five points sits where a LayerNorm's variance is small: torch fp32 autograd on the CPU is 5e-4 from fp64
+    # there (this path 2e-4); what the case checks is the 27 lanes beyond the batch
+    ("attention", "kdv", dict(hidden_dim=64, num_layers=2, num_heads=2, activation="tanh"), 5, 1e-3),
+    ("resnet", "cahn_hilliard", dict(hidden_dim=64, num_layers=2, num_blocks=2, activation="tanh"), 1, TOL),
+], ids=["attention-ch4-2x32-N33", "attention-kdv-2x64-N5", "resnet-ch4-N1"])
+def test_ragged_last_tile_under_layer_norm(arch, pde_name, kw, n, tol, dev):
+    """Found by tools/fuzz_parity.py: the lanes of the last tile beyond the batch used to run on zero coordinates.  With the
+    reference's zero-initialised first bias every feature of such a lane is equal, a LayerNorm there divides by sqrt(eps),
+    its high-order jets overflow fp32 after a few layers, and 0 (their cotangent) x inf = NaN reached every weight
+    gradient.  They now repeat the last point (lm_ew.h::load_coords)."""
+    import oracle as O
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import engine as E
+
+    spec = O.ArchSpec(architecture=arch, input_dim=2, **kw)
+    dom = ((-3.0, 3.0),) if pde_name == "kdv" else ((-1.0, 1.0),)
+    pde = O.PdeSpec(name=pde_name, dimension=1, domain=dom, time_domain=(0.0, 1.0),
+                    parameters={"kdv": {}, "cahn_hilliard": {"epsilon": 0.05}}[pde_name])
+    sd = O.init_state_dict(spec, seed=1)
+    torch.manual_seed(1)
+    x, t = O.sample_uniform(pde, max(n, 4) * 2)
+    x, t = x[:n].contiguous(), t[:n].contiguous()
+    r_o, L_o, g_o = _oracle64(spec, pde, sd, x, t)
+    prog, names = program_from_spec(spec, sd, dev)
+    pd = pde_desc_from_spec(pde)
+    flat = E.new_flat_grad(prog, dev)
+    r, s = E.residual_loss_grad(prog, pd, x.to(dev), t.to(dev), 1.0 / n, flat, want_residual=True)
+    assert torch.isfinite(flat).all(), "non-finite weight gradient"
+    assert rel_l2(r.cpu(), r_o, label="residual", tol=tol) <= tol
+    by = {k: g for k, g in zip(names, E.split_flat_grad(prog, flat)) if g is not None}
+    keys = [k for k in g_o if k in by]
+    got = torch.cat([by[k].flatten().cpu() for k in keys])
+    want = torch.cat([g_o[k].flatten() for k in keys])
+    e_g = rel_l2(got, want, label="gradient", tol=tol)
+    assert e_g <= tol, f"{e_g:.3e}"
