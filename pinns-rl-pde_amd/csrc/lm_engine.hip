@@ -207,6 +207,8 @@ struct Program {
   int rows[kMaxPack], cols[kMaxPack];  // logical shapes of the tensors the program uses (0 rows = unused)
   bool transpose[kMaxPack];
   bool enc_cols4[kMaxPack];            // (H x din) first-Linear weights are packed with 4 columns
+  bool matrix[kMaxPack];               // a GEMM weight: its packed rows are padded to 32 even when it has ONE row (a 1-wide
+                                       // layer); vectors (biases, LayerNorm parameters, the output layer) stay 1 x cols_p
   float ln_eps = 1e-5f;
   // merged attention branches (see lm_merge_pv_kernel): derived tensors live behind the fragment copies in the pack
   // table, at index derived_base + 2 j (weight) and + 1 (bias)
@@ -221,7 +223,8 @@ struct Program {
   } fuse_fwd[kMaxNodes], fuse_bwd[kMaxNodes];
 };
 
-void use_tensor(Program& P, int idx, int rows, int cols, bool enc4 = false, bool transpose = false) {
+void use_tensor(Program& P, int idx, int rows, int cols, bool enc4 = false, bool transpose = false, bool matrix = false) {
+  P.matrix[idx] = matrix;
   P.rows[idx] = rows;
   P.cols[idx] = cols;
   P.enc_cols4[idx] = enc4;
@@ -264,7 +267,7 @@ int build_program(const PinnNetDesc* d, Program& P, char* err, size_t en) {
     nd.Hin = Hin;
     nd.Hout = Hout;
     nd.add_node = add;
-    use_tensor(P, w, Hout, Hin);
+    use_tensor(P, w, Hout, Hin, false, false, true);
     use_tensor(P, b, 1, Hout);
     return P.n_nodes++;
   };
@@ -388,9 +391,9 @@ int build_program(const PinnNetDesc* d, Program& P, char* err, size_t en) {
     for (int l = 0; l < nl; ++l) {
       const int base = 2 + 16 * l;  // q(0,1) k(2,3) value(4,5) proj(6,7) LN_a(8,9) net.0(10,11) net.3(12,13) LN_f(14,15)
       // value and projection as ONE GEMM: za = (W_p W_v) h + (W_p b_v + b_p) + h
-      use_tensor(P, base + 4, H, H);
+      use_tensor(P, base + 4, H, H, false, false, true);  // lm_merge_pv_kernel reads both as H_p x H_p
       use_tensor(P, base + 5, 1, H);
-      use_tensor(P, base + 6, H, H);
+      use_tensor(P, base + 6, H, H, false, false, true);
       use_tensor(P, base + 7, 1, H);
       Program::Derived& dv = P.derived[P.n_derived];
       dv.wv = base + 4;
@@ -565,7 +568,11 @@ void make_layout(const Program& P, long long N, int K, bool bwd, bool determinis
       it.rows_p = round32(P.rows[i]);
       it.cols_p = 4;
     } else {
-      it.rows_p = P.rows[i] == 1 ? 1 : round32(P.rows[i]);
+      // A 1 x H GEMM weight (a layer of width 1) gets its 32 padded rows like any other: the weight-gradient kernels own the
+      // whole z_rows x v_rows block behind dW.  Packed as a vector, the block ran over the NEXT items of the gradient
+      // twin; harmless with float atomics (+= 0), but the deterministic reduction's plain "+= 0" on those addresses raced
+      // with the "+= db" of the bias that lives there and lost it about half the time (tools/fuzz_parity.py).
+      it.rows_p = (P.rows[i] == 1 && !P.matrix[i]) ? 1 : round32(P.rows[i]);
       it.cols_p = round32(P.cols[i]);
     }
     off += (size_t)it.rows_p * it.cols_p;

@@ -350,3 +350,36 @@ def test_ragged_last_tile_under_layer_norm(arch, pde_name, kw, n, tol, dev):
     want = torch.cat([g_o[k].flatten() for k in keys])
     e_g = rel_l2(got, want, label="gradient", tol=tol)
     assert e_g <= tol, f"{e_g:.3e}"
+
+
+def test_deterministic_mode_with_one_wide_layers(dev):
+    """Found by tools/fuzz_parity.py: a 1 x H GEMM weight used to be packed as a vector, so the 32 x 32 block the
+    weight-gradient kernels own behind dW ran over the following items of the packed gradient; with PINN_FLAG_DETERMINISTIC the
+    reduction's plain `+= 0` on those addresses raced with the `+= db` of the bias stored there and lost it about every
+    second call.  100 calls must be bit-identical and match the oracle."""
+    import oracle as O
+    from hip_helpers import pde_desc_from_spec, program_from_spec
+    from pinnrl_amd import engine as E
+
+    spec = O.ArchSpec(architecture="fourier", input_dim=2, hidden_dim=1, num_layers=4, mapping_size=8, scale=1.0, activation="tanh")
+    pde = O.PdeSpec(name="kdv", dimension=1, domain=((-3.0, 3.0),), time_domain=(0.0, 1.0), parameters={})
+    sd = O.init_state_dict(spec, seed=3)
+    torch.manual_seed(3)
+    x, t = O.sample_uniform(pde, 10)
+    x, t = x[:5].contiguous(), t[:5].contiguous()
+    r_o, L_o, g_o = _oracle64(spec, pde, sd, x, t)
+    prog, names = program_from_spec(spec, sd, dev)
+    prog.set_deterministic(True)
+    pd = pde_desc_from_spec(pde)
+    xd, td = x.to(dev), t.to(dev)
+    first = None
+    for _ in range(100):
+        flat = E.new_flat_grad(prog, dev)
+        E.residual_loss_grad(prog, pd, xd, td, 1.0 / 5, flat)
+        if first is None:
+            first = flat.clone()
+        assert torch.equal(flat, first), "deterministic mode: two calls differ"
+    by = {k: g for k, g in zip(names, E.split_flat_grad(prog, first)) if g is not None}
+    for k in g_o:
+        if k in by:
+            assert rel_l2(by[k].cpu(), g_o[k]) <= TOL, k
