@@ -342,6 +342,86 @@ def check_data_modes(manifest: dict):
                               "points": 97, "observations": 53, "loss_weights": {"residual": 1.0, "boundary": 10.0, "initial": 10.0, "data": 2.5}}
 
 
+LOSS_KINDS_IC = {
+    "burgers": [{"type": "sine", "amplitude": -1.0, "frequency": 1.0}, {"type": "tanh", "epsilon": 0.1}],
+    "heat": [{"type": "sin_exp_decay", "amplitude": 1.0, "frequency": 2.0}, {"type": "sine", "amplitude": 1.0, "frequency": 2.0}],
+    "allen_cahn": [{"type": "tanh", "epsilon": 0.1}],
+    "kdv": [{"type": "soliton", "speed": 1.0}],
+    "cahn_hilliard": [{"type": "tanh"}],
+    "wave": [{"type": "sine", "amplitude": 1.0, "frequency": 1.0}],
+    "convection": [{"type": "sine", "amplitude": 1.0, "frequency": 1.0}],
+    "black_scholes": [{"type": "call_option", "strike_price": 100.0}],
+    "pendulum": [{"type": "small_angle", "initial_angle": 0.5}, {"type": "sine", "amplitude": 0.5, "frequency": 1.0},
+                 {"type": "gaussian", "mean": 0.5, "std": 0.1}],
+}
+LOSS_KINDS_BC = [
+    {"dirichlet": {"type": "fixed", "value": 0.0}},
+    {"dirichlet": {"type": "fixed", "value": 0.5}},
+    {"periodic": {}},
+    {"neumann": {"type": "fixed", "value": 0.3}},
+    {"left": {"type": "fixed", "value": 0.2}, "right": {"type": "fixed", "value": -0.1}},
+]
+
+
+def loss_kinds_fixture(manifest: dict):
+    """`compute_loss` of all nine reference PDE classes under every deterministic initial-condition kind their own
+    `_create_boundary_condition` accepts and five boundary-condition dictionaries: the REFERENCE's loss terms and
+    d total / d theta for one small network, as a fixture the product's `compute_loss` is held to on the GPU
+    (tests/test_loss_kinds_gpu.py).  A combination the reference refuses is recorded with the exception type: the product
+    must refuse it too.  A combination whose terms depend on torch's RNG state is left out (CPU and device draws differ)."""
+    spec = O.ArchSpec("fourier", hidden_dim=32, num_layers=3, mapping_size=16, scale=2.0)
+    torch.manual_seed(51)
+    model = make_ref_model(spec)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [k for k, _ in model.named_parameters()]
+    arrays = {"sd/" + k: v.numpy() for k, v in sd.items()}
+    combos = []
+    for name, ics in LOSS_KINDS_IC.items():
+        dom, td, par, _ = PDE_DEFAULTS[name]
+        gen = torch.Generator().manual_seed(60 + len(combos))
+        x = torch.rand(97, 1, generator=gen) * (dom[0][1] - dom[0][0]) + dom[0][0]
+        t = torch.rand(97, 1, generator=gen) * (td[1] - td[0]) + td[0]
+        arrays[f"{name}/x"], arrays[f"{name}/t"] = x.numpy(), t.numpy()
+        for ic in ics:
+            for bc in LOSS_KINDS_BC:
+                key = f"{name}|{json.dumps(ic, sort_keys=True)}|{json.dumps(bc, sort_keys=True)}"
+                entry = {"pde": name, "initial_condition": ic, "boundary_conditions": bc, "domain": [list(d) for d in dom],
+                         "time_domain": list(td), "parameters": par, "key": key}
+                try:
+                    outs = []
+                    for seed in (1, 2):  # RNG-dependent terms differ between the two
+                        torch.manual_seed(seed)
+                        ref = PDE_CLS[name](config=PDEConfig(name=name, domain=[tuple(d) for d in dom], time_domain=tuple(td),
+                                                             parameters=dict(par), boundary_conditions=dict(bc), initial_condition=dict(ic),
+                                                             exact_solution={}, dimension=1, device=CPU))
+                        model.zero_grad()
+                        want = ref.compute_loss(model, x.clone(), t.clone())
+                        g = torch.autograd.grad(want["total"], [p for _, p in model.named_parameters()], allow_unused=True)
+                        g = torch.cat([(gi if gi is not None else torch.zeros_like(p)).flatten() for gi, (_, p) in zip(g, model.named_parameters())])
+                        outs.append(({k: float(v.detach()) for k, v in want.items() if torch.is_tensor(v) and v.numel() == 1}, g))
+                except Exception as e:  # the reference refuses the combination
+                    entry["raises"] = type(e).__name__
+                    combos.append(entry)
+                    continue
+                (l1, g1), (l2, g2) = outs
+                if any(abs(l1[k] - l2[k]) > 1e-7 * abs(l1[k]) for k in l1) or not torch.allclose(g1, g2, rtol=1e-6, atol=0):
+                    entry["rng_dependent"] = True
+                    combos.append(entry)
+                    continue
+                idx = len([c for c in combos if "index" in c])
+                entry["index"] = idx
+                for k, v in l1.items():
+                    arrays[f"{idx}/{k}"] = np.float32(v)
+                arrays[f"{idx}/grad"] = g1.numpy()
+                combos.append(entry)
+    np.savez_compressed(os.path.join(OUT, "loss_kinds.npz"), **arrays)
+    manifest["_loss_kinds"] = {"param_names": names, "combos": combos,
+                               "arch": {"architecture": "fourier", "hidden_dim": 32, "num_layers": 3, "mapping_size": 16, "scale": 2.0}}
+    n_ok = len([c for c in combos if "index" in c])
+    print(f"loss_kinds: {n_ok} combinations with numbers, {len([c for c in combos if 'raises' in c])} the reference refuses, "
+          f"{len([c for c in combos if c.get('rng_dependent')])} RNG-dependent (left out)")
+
+
 def quirk_witnesses(manifest: dict):
     """The behavioural quirks of SURVEY §0.3/§0.4, pinned as data."""
     w = {}
@@ -478,6 +558,7 @@ def main():
     check_data_modes(manifest)
     quirk_witnesses(manifest)
     sampler_fixtures(manifest)
+    loss_kinds_fixture(manifest)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True, default=float)
     print("wrote", len(cases), "fixtures to", OUT)
