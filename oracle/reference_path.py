@@ -454,6 +454,9 @@ def compute_residual(pde: PdeSpec, model_fn, x: Tensor, t: Tensor) -> Tensor:
         c = p.get("c", 1.0)
         return u_tt - c**2 * lap
     if name == "convection":  # convection_equation.py:43-78
+        if dim > 1:  # :66-76 differentiates u w.r.t. x[:, d:d+1], a slice that is not part of u's graph: torch raises this
+            raise RuntimeError("One of the differentiated Tensors appears to not have been used in the graph. "
+                               "Set allow_unused=True if this is the desired behavior.")
         x = x.detach().requires_grad_(True)
         t = t.detach().requires_grad_(True)
         u = model_fn(torch.cat([x, t], dim=1))

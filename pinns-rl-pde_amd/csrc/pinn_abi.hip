@@ -479,6 +479,8 @@ int pinn_num_tensors(const PinnNetDesc* net) {
 int pinn_pde_streams(const PinnPdeDesc* pde, int32_t* time_order, int32_t* space_order) {
   if (!pde || !time_order || !space_order) return fail(PINN_ERR_BAD_DESC, "null argument");
   int nt = 1, nx = 0;
+  if (pde->dimension > 1 && pde->kind == PINN_PDE_CONVECTION)  // convection_equation.py:66-76 differentiates u w.r.t. a SLICE of x: torch raises
+    return fail(PINN_ERR_UNSUPPORTED, "convection with dimension %d: the reference's residual raises for dimension > 1", pde->dimension);
   if (pde->dimension > 1) {
     nt = (pde->kind == PINN_PDE_WAVE || pde->kind == PINN_PDE_PENDULUM) ? 2 : 1;
   } else {

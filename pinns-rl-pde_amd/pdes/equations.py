@@ -464,9 +464,15 @@ class ConvectionEquation(PDEBase):
     def _prepare_model(self, model):
         pass
 
-    def _residual_from_jets(self, j, x, nt, nx):
+    def _pde_desc(self):
         if self.dimension > 1:
-            return j[1]
+            # convection_equation.py:66-76: for dimension > 1 the reference calls autograd.grad(u, x[:, dim:dim+1]) — a slice that is
+            # not part of u's graph — and torch raises exactly this RuntimeError.  Same type, same text, from every residual path.
+            raise RuntimeError("One of the differentiated Tensors appears to not have been used in the graph. "
+                               "Set allow_unused=True if this is the desired behavior.")
+        return super()._pde_desc()
+
+    def _residual_from_jets(self, j, x, nt, nx):
         return j[1] + self.velocity[0] * j[nt + 1]
 
     def _create_boundary_condition(self, bc_type, params):  # convection_equation.py:97-122

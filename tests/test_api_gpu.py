@@ -592,3 +592,21 @@ def test_live_snapshot_fields_match_the_oracle(dev, tmp_path):
     z = np.load(tmp_path / "live_snapshot.npz")
     assert set(z.files) == {"axis_x", "axis_y", "u_pred", "residual", "epoch", "dimension", "x_label", "y_label", "fixed_t"}
     assert int(z["epoch"]) == 3 and z["u_pred"].shape == (60, 60)
+
+
+def test_convection_in_two_dimensions_raises_like_the_reference(dev):
+    """convection_equation.py:66-76: for dimension > 1 the reference differentiates u with respect to a slice of x that is not
+    part of u's graph; torch raises RuntimeError.  Found by tools/fuzz_parity.py: this path used to return u_t silently."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import pinnrl_amd  # noqa: F401
+    from pinnrl_amd import pdes as P
+    import bench_configs as B
+
+    net = B.model("feedforward", 32, 2, "tanh", input_dim=3)
+    eq = P.ConvectionEquation(P.PDEConfig(name="convection", domain=[(-1.0, 1.0), (-1.0, 1.0)], time_domain=(0.0, 1.0),
+                                          parameters={"velocity": [1.0, 0.5]}, boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}},
+                                          initial_condition={"type": "sine"}, exact_solution={}, dimension=2, device=dev))
+    x, t = torch.rand(40, 2, device=dev), torch.rand(40, 1, device=dev)
+    with pytest.raises(RuntimeError, match="appears to not have been used in the graph"):
+        eq.compute_residual(net, x, t)

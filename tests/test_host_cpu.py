@@ -38,6 +38,9 @@ def test_descriptor_queries_without_a_gpu():
                        "pendulum": (2, 0), "convection": (1, 1)}.items():
         assert E.pde_streams(E.pde_desc(kind)) == want
     assert E.pde_streams(E.pde_desc("cahn_hilliard", dimension=2)) == (1, 0)  # reference drops 2-D spatial terms
+    # convection_equation.py:66-76 raises for dimension > 1 (autograd.grad w.r.t. a slice of x): refused here as well
+    with pytest.raises(Exception, match="convection"):
+        E.pde_streams(E.pde_desc("convection", dimension=2))
     spec, pde, sd, a, m = load_case("burgers_fourier_4x128")
     prog = E.NetProgram("fourier", "tanh", 2, [128, 128, 128, 1], list(sd.values()), [False] + [True] * 8, mapping_size=32)
     assert prog.flops_per_point() == 82304
