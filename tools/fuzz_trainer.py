@@ -54,6 +54,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--graph", action="store_true", help="second run = the step captured in a HIP graph (make_graphed_step) and replayed, "
+                    "first run = the eager launch list: same pinned batch, warm-up step included")
     args = ap.parse_args()
     rng = random.Random(args.seed)
     t_end = time.time() + args.seconds
@@ -79,6 +81,40 @@ def main():
         clip = rng.choice([0.0, 0.5, 1.0])
         lr = rng.choice([1e-3, 3e-3])
         tag = f"#{n_case} {name} {arch} w={w} L={layers} {act} {extra} N={n} clip={clip} lr={lr}"
+        if args.graph:
+            try:
+                thetas = []
+                for graphed in (False, True):
+                    net, eq, cfg = make(None, name, arch, w, layers, act, extra, clip, lr)
+                    tr = PDETrainer(net, eq, {}, cfg, device=B.dev)
+                    why = tr._manual_step_unsupported()
+                    if why is not None:
+                        raise RuntimeError("launch list refuses: " + str(why))
+                    tr._build_flat_state()
+                    torch.manual_seed(1000 + n_case)
+                    xb, tb = eq.generate_collocation_points(n, strategy="uniform")
+                    tr._sample = lambda m, xb=xb, tb=tb: (xb, tb)
+                    if graphed:
+                        replay, losses = tr.make_graphed_step(int(xb.shape[0]), warmup=1)
+                        for _ in range(2):
+                            replay()
+                        torch.cuda.synchronize()
+                        if not math.isfinite(float(losses["total"])):
+                            raise FloatingPointError("non-finite total loss after replay")
+                    else:
+                        for _ in range(3):  # the graphed run's warm-up step + two replays
+                            tr.train_step(xb, tb)
+                    thetas.append(torch.cat([p.detach().flatten().cpu() for p in net.parameters()]))
+            except Exception as e:
+                bad.append(f"{tag} raised {type(e).__name__}: {str(e)[:160]}")
+                print(f"{tag}: FAIL raised {type(e).__name__}: {str(e)[:160]}", flush=True)
+                continue
+            e_t = rel(thetas[1], thetas[0])
+            ok = math.isfinite(e_t) and e_t <= 2e-4
+            print(f"{tag}: graph replay vs eager launch list theta {e_t:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+            if not ok:
+                bad.append(f"{tag} graph vs eager theta {e_t:.2e}")
+            continue
         try:
             runs = []
             for manual in (False, True):
