@@ -362,14 +362,24 @@ class PDEBase:
         x_orders = [i for i in sorted(spatial_derivatives or []) if i != 0]
         nt = len(t_orders)
         nx = len(x_orders) if self.dimension == 1 else 0
-        knt, knx = _pick_stream_set(nt, nx)
-        jets = jets_fn(x, t, knt, knx)
+        try:
+            knt, knx = _pick_stream_set(nt, nx)
+            jets = jets_fn(x, t, knt, knx)
+            t_jets, x_jets = jets, jets
+        except NotImplementedError:
+            # two time orders together with three or four space orders: no compiled stream set holds both directions.  The
+            # streams are pure directional derivatives, so the two directions come from two launches (the reference allows the
+            # request: pde_base.py:614-627 only caps the orders)
+            a, _ = _pick_stream_set(nt, 0)
+            knt, knx = _pick_stream_set(0, nx)
+            t_jets = jets_fn(x, t, a, 0)
+            x_jets = jets = jets_fn(x, t, knt, knx)
         out: Dict[str, torch.Tensor] = {}
         for c, i in enumerate(t_orders, start=1):
-            out["dt" if i == 1 else f"dt{i}"] = jets[c].unsqueeze(1)
+            out["dt" if i == 1 else f"dt{i}"] = t_jets[c].unsqueeze(1)
         if self.dimension == 1:
             for c, i in enumerate(x_orders, start=1):
-                out["dx" if i == 1 else f"dx{i}"] = jets[knt + c].unsqueeze(1)
+                out["dx" if i == 1 else f"dx{i}"] = x_jets[knt + c].unsqueeze(1)
             if spatial_derivatives and 2 in spatial_derivatives:
                 out["laplacian"] = out["dx2"]
         elif x_orders:

@@ -87,6 +87,15 @@ def test_compute_derivatives_keys_and_values(tag, dev):
         pde.compute_derivatives(model, x, t, temporal_derivatives=[3])
     with pytest.raises(ValueError):
         pde.compute_derivatives(model, x, t, spatial_derivatives=[5])
+    # two time orders with four space orders: no single compiled stream set; served by two launches (tools/fuzz_derivs.py)
+    import oracle as O
+    sd64 = {k: v.double() for k, v in sd.items()}
+    want = O.compute_derivatives(lambda z: O.network_forward(spec, sd64, z), torch.from_numpy(a["x"]).double(), torch.from_numpy(a["t"]).double(),
+                                 temporal_derivatives=[1, 2], spatial_derivatives=[1, 2, 3, 4])
+    got = pde.compute_derivatives(model, x, t, temporal_derivatives=[1, 2], spatial_derivatives=[1, 2, 3, 4])
+    assert set(got) == {k for k in want if not k.startswith("_")}
+    for k in got:
+        assert rel_l2(got[k].detach().cpu(), want[k].detach()) <= 5e-5, k
 
 
 @pytest.mark.parametrize("tag", ["allen_cahn_resnet_2x32", "cahn_hilliard2d_attention_2x32"])
