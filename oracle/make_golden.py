@@ -422,6 +422,56 @@ def loss_kinds_fixture(manifest: dict):
           f"{len([c for c in combos if c.get('rng_dependent')])} RNG-dependent (left out)")
 
 
+EXACT_KINDS = {
+    "burgers": [{}, {"type": "cole_hopf"}, {"type": "cole_hopf", "viscosity": 0.05}, {"type": "tanh", "epsilon": 0.1}],
+    "heat": [{}, {"type": "sin_exp_decay", "amplitude": 1.0, "frequency": 2.0}, {"type": "sine", "amplitude": 0.5, "frequency": 1.0}],
+    "allen_cahn": [{}, {"type": "tanh"}],
+    "kdv": [{}, {"type": "soliton", "speed": 1.0}],
+    "cahn_hilliard": [{}, {"type": "tanh"}],
+    "wave": [{}, {"type": "sine", "amplitude": 1.0, "frequency": 1.0}],
+    "convection": [{}, {"type": "sine", "amplitude": 1.0, "frequency": 1.0}],
+    "black_scholes": [{}, {"type": "call_option", "strike_price": 100.0}],
+    "pendulum": [{}, {"type": "small_angle", "initial_angle": 0.5}, {"type": "sine", "amplitude": 0.5, "frequency": 1.0}],
+}
+
+
+def exact_solution_fixture(manifest: dict):
+    """`exact_solution(x, t)` of the nine reference classes (what `validate` and the live-snapshot fields compare against) under
+    every `exact_solution` dictionary kind each class branches on: the reference's values on 64 points, or the exception type it
+    raises.  tests/test_exact_solutions_cpu.py holds the product's classes to them on a CPU device."""
+    arrays, entries = {}, []
+    for name, kinds in EXACT_KINDS.items():
+        dom, td, par, ic = PDE_DEFAULTS[name]
+        gen = torch.Generator().manual_seed(90 + len(entries))
+        x = torch.rand(64, 1, generator=gen) * (dom[0][1] - dom[0][0]) + dom[0][0]
+        t = torch.rand(64, 1, generator=gen) * (td[1] - td[0]) + td[0]
+        arrays[f"{name}/x"], arrays[f"{name}/t"] = x.numpy(), t.numpy()
+        for ex in kinds:
+            e = {"pde": name, "exact_solution": ex, "domain": [list(d) for d in dom], "time_domain": list(td), "parameters": par,
+                 "initial_condition": ic}
+            try:
+                ref = PDE_CLS[name](config=PDEConfig(name=name, domain=[tuple(d) for d in dom], time_domain=tuple(td), parameters=dict(par),
+                                                     boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}},
+                                                     initial_condition=dict(ic), exact_solution=dict(ex), dimension=1, device=CPU))
+                try:
+                    u = ref.exact_solution(x.clone(), t.clone())
+                except RuntimeError:  # Burgers' Cole-Hopf form differentiates phi w.r.t. x by autograd: it needs x.requires_grad
+                    u = ref.exact_solution(x.clone().requires_grad_(True), t.clone())
+                    e["reference_needs_x_requires_grad"] = True
+                if u is None:  # "if not self.config.exact_solution: return None"
+                    e["returns_none"] = True
+                else:
+                    e["index"] = len([c for c in entries if "index" in c])
+                    arrays[f'{e["index"]}/u'] = u.detach().numpy()
+            except Exception as err:
+                e["raises"] = type(err).__name__
+            entries.append(e)
+    np.savez_compressed(os.path.join(OUT, "exact_solutions.npz"), **arrays)
+    manifest["_exact_solutions"] = entries
+    print(f"exact_solutions: {len([c for c in entries if 'index' in c])} with values, {len([c for c in entries if c.get('returns_none')])} None, "
+          f"{len([c for c in entries if 'raises' in c])} the reference raises on: {[(c['pde'], c['exact_solution'].get('type'), c['raises']) for c in entries if 'raises' in c]}")
+
+
 def quirk_witnesses(manifest: dict):
     """The behavioural quirks of SURVEY §0.3/§0.4, pinned as data."""
     w = {}
@@ -559,6 +609,7 @@ def main():
     quirk_witnesses(manifest)
     sampler_fixtures(manifest)
     loss_kinds_fixture(manifest)
+    exact_solution_fixture(manifest)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True, default=float)
     print("wrote", len(cases), "fixtures to", OUT)
