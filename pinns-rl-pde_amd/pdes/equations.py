@@ -104,6 +104,38 @@ class HeatEquation(PDEBase):
             return j[1]
         return j[1] - self.alpha * j[nt + 1]
 
+    def validate(self, model, num_points: int = 5000) -> Dict[str, Any]:  # heat_equation.py:296-372
+        """The heat class's own validation: the three error metrics of the base class, a finiteness check, the optional
+        `physical_bounds` of the configuration, the periodic-boundary mismatch when a periodic condition is configured (at
+        x = 0 and x = 1, as the reference hard-codes), `validation_passed` and `validation_messages`."""
+        passed, messages, metrics = True, [], {}
+        x, t = self.generate_collocation_points(num_points)
+        u_pred = model(torch.cat([x, t], dim=1))
+        if not bool(torch.isfinite(u_pred).all()):
+            passed = False
+            messages.append("Error: Solution contains NaN or Inf values")
+        err = torch.abs(u_pred - self.exact_solution(x, t))
+        metrics.update({"l2_error": torch.mean(err**2).item(), "max_error": torch.max(err).item(), "mean_error": torch.mean(err).item()})
+        if hasattr(self.config, "physical_bounds"):
+            lo = self.config.physical_bounds.get("min_temperature", float("-inf"))
+            hi = self.config.physical_bounds.get("max_temperature", float("inf"))
+            if bool(torch.any(u_pred < lo)) or bool(torch.any(u_pred > hi)):
+                passed = False
+                messages.append(f"Error: Solution violates physical temperature bounds [{lo}, {hi}]")
+        if "periodic" in self.boundary_conditions:
+            n = num_points // 10
+            tb = torch.linspace(0, self.config.time_domain[1], n, device=self.device).reshape(-1, 1)
+            u_l = model(torch.cat([torch.zeros(n, 1, device=self.device), tb], dim=1))
+            u_r = model(torch.cat([torch.ones(n, 1, device=self.device), tb], dim=1))
+            periodic_error = torch.mean((u_l - u_r) ** 2).item()
+            metrics["periodic_bc_error"] = periodic_error
+            if periodic_error > 1e-3:
+                passed = False
+                messages.append(f"Warning: Periodic boundary condition error ({periodic_error:.2e}) exceeds tolerance")
+        metrics["validation_passed"] = passed
+        metrics["validation_messages"] = messages
+        return metrics
+
     def _calculate_decay_rate(self, k: float):  # heat_equation.py:40-52
         L = self.config.domain[0][1] - self.config.domain[0][0]
         return self.alpha * (2 * torch.pi * k / L) ** 2

@@ -619,3 +619,26 @@ def test_convection_in_two_dimensions_raises_like_the_reference(dev):
     x, t = torch.rand(40, 2, device=dev), torch.rand(40, 1, device=dev)
     with pytest.raises(RuntimeError, match="appears to not have been used in the graph"):
         eq.compute_residual(net, x, t)
+
+
+def test_heat_validate_has_the_reference_s_fields(dev):
+    """HeatEquation.validate (heat_equation.py:296-372): error metrics, periodic-boundary mismatch, verdict and messages."""
+    cfg, model, pde, (spec, ps, sd, a, m) = build("heat_fourier_4x128", dev)
+    torch.manual_seed(3)
+    out = pde.validate(model, num_points=400)
+    assert {"l2_error", "max_error", "mean_error", "validation_passed", "validation_messages"} <= set(out)
+    assert isinstance(out["validation_passed"], bool) and isinstance(out["validation_messages"], list)
+    assert out["max_error"] >= out["mean_error"] >= 0.0 and math.isfinite(out["l2_error"])
+    from pinnrl_amd import pdes as P
+    pc = P.PDEConfig(name="heat", domain=[(0.0, 1.0)], time_domain=(0.0, 1.0), parameters={"alpha": 0.01}, boundary_conditions={"periodic": {}},
+                     initial_condition={"type": "sine", "amplitude": 1.0, "frequency": 2.0}, exact_solution={"type": "sine", "amplitude": 1.0, "frequency": 2.0},
+                     dimension=1, device=dev)
+    pc.physical_bounds = {"min_temperature": -1e-9, "max_temperature": 1e-9}
+    eq = P.HeatEquation(pc)
+    out = eq.validate(model, num_points=400)
+    n = 40
+    tb = torch.linspace(0, 1.0, n, device=dev).reshape(-1, 1)
+    with torch.no_grad():
+        want = torch.mean((model(torch.cat([torch.zeros(n, 1, device=dev), tb], 1)) - model(torch.cat([torch.ones(n, 1, device=dev), tb], 1))) ** 2).item()
+    assert abs(out["periodic_bc_error"] - want) <= 1e-6 * max(want, 1e-12)
+    assert out["validation_passed"] is False and any("physical temperature bounds" in s for s in out["validation_messages"])
