@@ -466,6 +466,19 @@ def exact_solution_fixture(manifest: dict):
             except Exception as err:
                 e["raises"] = type(err).__name__
             entries.append(e)
+    # the pendulum class's closed-form helpers (pendulum_equation.py:232-289)
+    pend = []
+    dom, td, par, _ = PDE_DEFAULTS["pendulum"]
+    x, t = torch.from_numpy(arrays["pendulum/x"]), torch.from_numpy(arrays["pendulum/t"])
+    for ic in LOSS_KINDS_IC["pendulum"] + [{"type": "gaussian", "amplitude": 0.7, "center": 0.4, "sigma": 0.2}]:
+        for bc in ({"dirichlet": {"type": "fixed", "value": 0.25}}, {"dirichlet": {"type": "periodic"}}):
+            ref = PendulumEquation(config=PDEConfig(name="pendulum", domain=[tuple(d) for d in dom], time_domain=tuple(td), parameters=dict(par),
+                                                    boundary_conditions=dict(bc), initial_condition=dict(ic), exact_solution={}, dimension=1, device=CPU))
+            i = len(pend)
+            arrays[f"pendulum_ic/{i}"] = ref.compute_initial_condition(x.clone()).numpy()
+            arrays[f"pendulum_bc/{i}"] = ref.compute_boundary_condition(x.clone(), t.clone()).numpy()
+            pend.append({"initial_condition": ic, "boundary_conditions": bc, "index": i})
+    manifest["_pendulum_helpers"] = pend
     np.savez_compressed(os.path.join(OUT, "exact_solutions.npz"), **arrays)
     manifest["_exact_solutions"] = entries
     print(f"exact_solutions: {len([c for c in entries if 'index' in c])} with values, {len([c for c in entries if c.get('returns_none')])} None, "

@@ -11,6 +11,7 @@ must stay in the autograd graph.
 
 from __future__ import annotations
 
+import math
 from typing import Any, Dict
 
 import torch
@@ -624,3 +625,40 @@ class PendulumEquation(PDEBase):
             A, f = self.config.exact_solution.get("amplitude", 1.0), self.config.exact_solution.get("frequency", 1.0)
             return A * torch.sin(f * (x + t))
         raise ValueError(f"Unknown exact solution type: {kind}")
+
+    # ---- the pendulum class's own utilities (pendulum_equation.py:158-212, 232-289): all on the derivative path
+    def compute_energy(self, model, x, t):
+        """Kinetic + potential energy per point: L^2 (du/dt)^2 / 2 + g L (1 - cos u)."""
+        d = self.compute_derivatives(model, x, t, temporal_derivatives=[1], spatial_derivatives=set())
+        u = model(torch.cat([x, t], dim=1))
+        return 0.5 * self.L * self.L * d["dt"].pow(2) + self.g * self.L * (1 - torch.cos(u))
+
+    def compute_phase_space(self, model, x, t):
+        """(theta, d theta / dt)."""
+        d = self.compute_derivatives(model, x, t, temporal_derivatives=[1])
+        return model(torch.cat([x, t], dim=1)), d["dt"]
+
+    def compute_initial_condition(self, x):
+        ic = self.config.initial_condition
+        if not ic:
+            return None
+        kind = ic.get("type", "small_angle")
+        if kind == "small_angle":
+            return torch.full_like(x, ic.get("initial_angle", 0.1))
+        if kind == "sine":
+            return ic.get("amplitude", 1.0) * torch.sin(ic.get("frequency", 1.0) * x)
+        if kind == "gaussian":
+            A, c, sg = ic.get("amplitude", 1.0), ic.get("center", 0.0), ic.get("sigma", 0.1)
+            return A * torch.exp(-((x - c) ** 2) / (2 * sg**2))
+        raise ValueError(f"Unknown initial condition type: {kind}")
+
+    def compute_boundary_condition(self, x, t):
+        bcs = self.config.boundary_conditions
+        if not bcs:
+            return None
+        kind = bcs.get("dirichlet", {}).get("type", "fixed")
+        if kind == "fixed":
+            return torch.full_like(x, bcs["dirichlet"].get("value", 0.0))
+        if kind == "periodic":
+            return torch.sin(2 * math.pi * x)
+        raise ValueError(f"Unknown boundary condition type: {kind}")

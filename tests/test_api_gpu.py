@@ -642,3 +642,20 @@ def test_heat_validate_has_the_reference_s_fields(dev):
         want = torch.mean((model(torch.cat([torch.zeros(n, 1, device=dev), tb], 1)) - model(torch.cat([torch.ones(n, 1, device=dev), tb], 1))) ** 2).item()
     assert abs(out["periodic_bc_error"] - want) <= 1e-6 * max(want, 1e-12)
     assert out["validation_passed"] is False and any("physical temperature bounds" in s for s in out["validation_messages"])
+
+
+def test_pendulum_energy_and_phase_space(dev):
+    """PendulumEquation.compute_energy / compute_phase_space (pendulum_equation.py:158-212) against the oracle's u and du/dt."""
+    import oracle as O
+
+    cfg, model, pde, (spec, ps, sd, a, m) = build("pendulum_siren_3x32", dev)
+    x, t = torch.from_numpy(a["x"]).to(dev), torch.from_numpy(a["t"]).to(dev)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    d = O.compute_derivatives(lambda z: O.network_forward(spec, sd64, z), torch.from_numpy(a["x"]).double(), torch.from_numpy(a["t"]).double(),
+                              temporal_derivatives=[1], spatial_derivatives=None)
+    u = O.network_forward(spec, sd64, torch.cat([torch.from_numpy(a["x"]), torch.from_numpy(a["t"])], 1).double()).detach()
+    g, L = ps.parameters["g"], ps.parameters["L"]
+    want_e = 0.5 * L * L * d["dt"].detach() ** 2 + g * L * (1 - torch.cos(u))
+    th, om = pde.compute_phase_space(model, x, t)
+    assert rel_l2(th.detach().cpu(), u) <= TOL and rel_l2(om.detach().cpu(), d["dt"].detach()) <= 2 * TOL
+    assert rel_l2(pde.compute_energy(model, x, t).detach().cpu(), want_e) <= 5 * TOL

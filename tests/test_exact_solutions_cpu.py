@@ -52,3 +52,22 @@ def test_exact_solution_equals_the_reference(e, arrays):
     want = torch.from_numpy(arrays[f'{e["index"]}/u'])
     assert u.shape == want.shape
     assert torch.allclose(u, want, rtol=2e-6, atol=1e-7), float((u - want).abs().max())
+
+
+with open(os.path.join(GOLD, "manifest.json")) as f:
+    PEND = json.load(f)["_pendulum_helpers"]
+
+
+@pytest.mark.parametrize("e", PEND, ids=[f'{e["initial_condition"]["type"]}-{e["boundary_conditions"]["dirichlet"]["type"]}-{e["index"]}' for e in PEND])
+def test_pendulum_closed_form_helpers_equal_the_reference(e, arrays):
+    """PendulumEquation.compute_initial_condition / compute_boundary_condition (pendulum_equation.py:232-289)."""
+    import pinnrl_amd  # noqa: F401
+    from pinnrl_amd import pdes as P
+
+    x, t = torch.from_numpy(arrays["pendulum/x"]), torch.from_numpy(arrays["pendulum/t"])
+    pde = P.PendulumEquation(P.PDEConfig(name="pendulum", domain=[(0.0, 1.0)], time_domain=(0.0, 10.0), parameters={"g": 9.81, "L": 1.0},
+                                         boundary_conditions=dict(e["boundary_conditions"]), initial_condition=dict(e["initial_condition"]),
+                                         exact_solution={}, dimension=1, device=torch.device("cpu")))
+    i = e["index"]
+    assert torch.allclose(pde.compute_initial_condition(x.clone()), torch.from_numpy(arrays[f"pendulum_ic/{i}"]), rtol=2e-6, atol=1e-7)
+    assert torch.allclose(pde.compute_boundary_condition(x.clone(), t.clone()), torch.from_numpy(arrays[f"pendulum_bc/{i}"]), rtol=2e-6, atol=1e-7)
