@@ -479,6 +479,16 @@ def exact_solution_fixture(manifest: dict):
             arrays[f"pendulum_bc/{i}"] = ref.compute_boundary_condition(x.clone(), t.clone()).numpy()
             pend.append({"initial_condition": ic, "boundary_conditions": bc, "index": i})
     manifest["_pendulum_helpers"] = pend
+    # HeatEquation.exact_solution_sine (heat_equation.py:197-212), 1-D and 2-D
+    for dim in (1, 2):
+        hd, htd, hpar, hic = PDE_DEFAULTS["heat"]
+        ref = HeatEquation(config=PDEConfig(name="heat", domain=[tuple(hd[0])] * dim, time_domain=tuple(htd), parameters=dict(hpar),
+                                            boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}}, initial_condition=dict(hic),
+                                            exact_solution={"type": "sine", "amplitude": 0.8, "frequency": 1.5}, dimension=dim, device=CPU))
+        gen = torch.Generator().manual_seed(200 + dim)
+        hx, ht = torch.rand(32, dim, generator=gen), torch.rand(32, 1, generator=gen)
+        arrays[f"heat_sine/{dim}/x"], arrays[f"heat_sine/{dim}/t"] = hx.numpy(), ht.numpy()
+        arrays[f"heat_sine/{dim}/u"] = ref.exact_solution_sine(hx.clone(), ht.clone()).numpy()
     np.savez_compressed(os.path.join(OUT, "exact_solutions.npz"), **arrays)
     manifest["_exact_solutions"] = entries
     print(f"exact_solutions: {len([c for c in entries if 'index' in c])} with values, {len([c for c in entries if c.get('returns_none')])} None, "

@@ -137,6 +137,17 @@ class HeatEquation(PDEBase):
         metrics["validation_messages"] = messages
         return metrics
 
+    def exact_solution_sine(self, x, t):  # heat_equation.py:197-212 ("legacy" form: wave number k pi, not 2 pi k / L)
+        A = self.config.exact_solution.get("amplitude", 1.0)
+        k = self.config.exact_solution.get("frequency", 2.0)
+        decay = torch.exp(-self.alpha * (k * torch.pi) ** 2 * t)
+        if self.dimension == 1:
+            return A * decay * torch.sin(k * torch.pi * x)
+        sol = torch.ones_like(x[:, 0:1])
+        for d in range(self.dimension):
+            sol = sol * (A * decay * torch.sin(k * torch.pi * x[:, d : d + 1]))
+        return sol
+
     def _calculate_decay_rate(self, k: float):  # heat_equation.py:40-52
         L = self.config.domain[0][1] - self.config.domain[0][0]
         return self.alpha * (2 * torch.pi * k / L) ** 2

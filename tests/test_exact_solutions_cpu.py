@@ -71,3 +71,17 @@ def test_pendulum_closed_form_helpers_equal_the_reference(e, arrays):
     i = e["index"]
     assert torch.allclose(pde.compute_initial_condition(x.clone()), torch.from_numpy(arrays[f"pendulum_ic/{i}"]), rtol=2e-6, atol=1e-7)
     assert torch.allclose(pde.compute_boundary_condition(x.clone(), t.clone()), torch.from_numpy(arrays[f"pendulum_bc/{i}"]), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dim", [1, 2])
+def test_heat_legacy_sine_solution_equals_the_reference(dim, arrays):
+    """HeatEquation.exact_solution_sine (heat_equation.py:197-212)."""
+    import pinnrl_amd  # noqa: F401
+    from pinnrl_amd import pdes as P
+
+    pde = P.HeatEquation(P.PDEConfig(name="heat", domain=[(0.0, 1.0)] * dim, time_domain=(0.0, 1.0), parameters={"alpha": 0.01},
+                                     boundary_conditions={"dirichlet": {"type": "fixed", "value": 0.0}},
+                                     initial_condition={"type": "sine", "amplitude": 1.0, "frequency": 2.0},
+                                     exact_solution={"type": "sine", "amplitude": 0.8, "frequency": 1.5}, dimension=dim, device=torch.device("cpu")))
+    x, t = torch.from_numpy(arrays[f"heat_sine/{dim}/x"]), torch.from_numpy(arrays[f"heat_sine/{dim}/t"])
+    assert torch.allclose(pde.exact_solution_sine(x, t), torch.from_numpy(arrays[f"heat_sine/{dim}/u"]), rtol=2e-6, atol=1e-7)
