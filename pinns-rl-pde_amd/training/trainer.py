@@ -502,6 +502,9 @@ class PDETrainer:
             s = s.clone()
         return {"residual": s[0], "boundary": s[1], "initial": s[2], "total": s[3]}
 
+    def get_training_history(self):  # trainer.py:966-972
+        return self.history
+
     def make_graphed_step(self, batch_size: int, warmup: int = 2):
         """Capture ONE whole training step in a HIP graph and return `(replay, losses)`: `replay()` runs a step on a
         fresh device-side sample, `losses` is the dict of STATIC loss tensors it refreshes.
